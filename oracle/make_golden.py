@@ -1,0 +1,195 @@
+"""Generates tests/golden/*.npz by RUNNING THE REFERENCE ITSELF on CPU (fp32).
+
+Run in the build container only (needs /root/reference):   python oracle/make_golden.py
+
+The reference has no golden vectors of its own, so these fixtures are the
+pin for the oracle (oracle/mpi_oracle.c), for the host-side geometry mirror and for the HIP path:
+
+  render_*.npz   inputs (rgba by seed via oracle.synth_rgba, camera tensors exactly as the
+                 reference's `sample_cam_poses` produced them) + outputs of the reference
+                 `MPIRenderer.render` / `MPI.forward` (gmpi/core/mpi_renderer.py:387, mpi.py:308)
+  geometry.npz   plane depths / dhws / c2w / rays / sampled poses of the reference's host-side
+                 helpers (mpi_utils.py:21,787,652; cam_utils.py:734; camera.py:182;
+                 mpi_renderer.py:337) for the dataset presets
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import oracle  # noqa: E402
+import ref_import  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+# name, preset, D, (Ht, Wt), S (render size), B views, align_corners, pose spec, rgba options
+RENDER_CASES = [
+    dict(name="ffhq_d8_32_ac1", preset="FFHQ", D=8, tex=(32, 32), S=32, B=2, ac=True, pose="random", seed=11),
+    dict(name="ffhq_d8_32_ac0", preset="FFHQ", D=8, tex=(32, 32), S=32, B=2, ac=False, pose="random", seed=12),
+    dict(name="ffhq_d6_tex48x40_extreme", preset="FFHQ", D=6, tex=(48, 40), S=24, B=2, ac=True,
+         pose=[(0.578, 0.254), (-0.578, -0.254)], seed=13),
+    dict(name="metfaces_d16_64_bf16", preset="MetFaces", D=16, tex=(64, 64), S=64, B=1, ac=True, pose="random",
+         seed=14, bf16=True, last_alpha_one=True),
+    dict(name="afhq_d5_tex20_img36", preset="AFHQCat", D=5, tex=(20, 20), S=36, B=1, ac=False, pose="random",
+         seed=15),
+    dict(name="ffhq_d4_alpha01", preset="FFHQ", D=4, tex=(16, 16), S=16, B=1, ac=True, pose=[(0.1, -0.05)],
+         seed=16, alpha_binary=True),
+    dict(name="ffhq_d32_256_cfg1", preset="FFHQ", D=32, tex=(256, 256), S=256, B=1, ac=True, pose="random",
+         seed=1000),  # BASELINE.json configs[0]
+]
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def build_rgba(case):
+    Ht, Wt = case["tex"]
+    rgba = oracle.synth_rgba(case["seed"], (case["B"], case["D"], 4, Ht, Wt),
+                             last_alpha_one=case.get("last_alpha_one", False), bf16_round=case.get("bf16", False))
+    if case.get("alpha_binary"):
+        rgba[:, :, 3] = (rgba[:, :, 3] > 0.5).astype(np.float32)  # exercises a==1 (the 1e-10 term) and a==0
+    return rgba
+
+
+def run_render_case(ns, case):
+    with quiet():
+        r = ref_import.make_reference_renderer(ns, case["preset"], case["D"], align_corners=case["ac"])
+        r.set_cam(r.cam_fov, case["S"], case["S"])
+    B = case["B"]
+    torch.manual_seed(case["seed"])
+    if case["pose"] == "random":
+        cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    else:
+        yaws = torch.tensor([[p[0]] for p in case["pose"]], dtype=torch.float32)
+        pitches = torch.tensor([[p[1]] for p in case["pose"]], dtype=torch.float32)
+        cam = r.sample_cam_poses(B, 0.0, 0.0, 0.0, 0.0, False, given_yaws=yaws, given_pitches=pitches)
+    keys = ["batch_yaws", "batch_pitches", "batch_tf_c2w", "batch_ray_dir", "batch_eye_pos", "batch_z_dir"]
+    infos = dict(zip(keys, cam))
+    rgba = build_rgba(case)
+    t_rgba = torch.from_numpy(rgba)
+    if case.get("bf16"):
+        t_rgba = t_rgba.to(torch.bfloat16)  # exact (values were rounded); reference upcasts, mpi_renderer.py:446
+    with quiet():
+        rgb, depth, c2w, angles = r.render(t_rgba, case["S"], case["S"], given_cam_infos=infos,
+                                            assert_not_out_of_last_plane=True)
+    # second formulation of the same composite (mpi.py:218-306) as an extra pin
+    dhw = r.dynamic_mpi_plane_dhws.reshape(1, -1, 3).expand(B, -1, -1)
+    with quiet():
+        c_old, d_old = r.mpi.old_forward(batch_rgba=t_rgba.float(), batch_dhw=dhw, batch_ray_dir=cam[3],
+                                         batch_eye_pos=cam[4], batch_z_dir=cam[5], separate_background=None)
+    meta = {k: v for k, v in case.items()}
+    np.savez(
+        os.path.join(OUT, f"render_{case['name']}.npz"),
+        meta=json.dumps(meta),
+        dhw=dhw.contiguous().numpy().astype(np.float32),
+        ray_dir=torch.cat(cam[3]).numpy(), eye=torch.cat(cam[4]).numpy(), zdir=torch.cat(cam[5]).numpy(),
+        yaws=cam[0].numpy(), pitches=cam[1].numpy(), c2w=cam[2].numpy(),
+        ref_rgb_pm1=rgb.numpy(), ref_depth=depth.numpy(), ref_angles=angles.numpy(),
+        ref_old_color01=c_old.numpy(), ref_old_depth=d_old.numpy(),
+    )
+    print("wrote", case["name"], "rgb range", float(rgb.min()), float(rgb.max()))
+
+
+def run_multiview_case(ns):
+    """MPI.forward called directly with a ragged views-per-MPI list (mpi.py:331-354): M=2 MPIs, (2,1) views."""
+    with quiet():
+        r = ref_import.make_reference_renderer(ns, "FFHQ", 5)
+        r.set_cam(r.cam_fov, 20, 20)
+    torch.manual_seed(21)
+    cam = r.sample_cam_poses(3, 0.0, 0.289, 0.0, 0.127, True)
+    rgba = oracle.synth_rgba(21, (2, 5, 4, 24, 28))
+    dhw = r.dynamic_mpi_plane_dhws.reshape(1, -1, 3).expand(2, -1, -1).contiguous()
+    ray = [torch.cat(cam[3][:2]), cam[3][2]]
+    eye = [torch.cat(cam[4][:2]), cam[4][2]]
+    zd = [torch.cat(cam[5][:2]), cam[5][2]]
+    color, depth = r.mpi(batch_rgba=torch.from_numpy(rgba), batch_dhw=dhw, batch_ray_dir=ray, batch_eye_pos=eye,
+                         batch_z_dir=zd, separate_background=None, assert_not_out_of_last_plane=True)
+    np.savez(os.path.join(OUT, "forward_ragged_views.npz"),
+             meta=json.dumps(dict(seed=21, M=2, D=5, tex=(24, 28), S=20, views_per_mpi=[2, 1], ac=True)),
+             dhw=dhw.numpy(), ray_dir=torch.cat(cam[3]).numpy(), eye=torch.cat(cam[4]).numpy(),
+             zdir=torch.cat(cam[5]).numpy(), view_to_mpi=np.array([0, 0, 1], np.int32),
+             ref_color01=color.numpy(), ref_depth=depth.numpy())
+    print("wrote forward_ragged_views")
+
+
+def run_geometry(ns):
+    out = {}
+    meta = {"presets": {}, "poses": []}
+    for preset in ("FFHQ", "MetFaces", "AFHQCat"):
+        for confined in (True, False):
+            for D in (4, 32, 96):
+                if not confined and D != 32:
+                    continue
+                with quiet():
+                    r = ref_import.make_reference_renderer(ns, preset, D, confined=confined)
+                key = f"dhw_{preset}_{'conf' if confined else 'free'}_{D}"
+                out[key] = r.static_mpi_plane_dhws.numpy()
+                meta["presets"][key] = dict(preset=preset, confined=confined, D=D)
+    for method in ("uniform", "log-uniform", "sqrt", "squared", "inverse"):
+        out[f"dist_{method}"] = ns.mpi_utils.sample_distance(0.95, 1.12, 12, method)
+    # c2w + rays for given angles, 3 sphere setups
+    with quiet():
+        r = ref_import.make_reference_renderer(ns, "FFHQ", 4)
+    for i, (S, yaw, pitch) in enumerate([(8, 0.0, 0.0), (8, 0.3, -0.1), (16, -0.578, 0.254), (5, 0.01, 0.2)]):
+        with quiet():
+            r.set_cam(r.cam_fov, S, S)
+        cam = r.sample_cam_poses(1, 0.0, 0.0, 0.0, 0.0, False, given_yaws=torch.tensor([[yaw]]),
+                                 given_pitches=torch.tensor([[pitch]]))
+        out[f"pose{i}_c2w"] = cam[2].numpy()
+        out[f"pose{i}_ray"] = cam[3][0].numpy()
+        out[f"pose{i}_eye"] = cam[4][0].numpy()
+        out[f"pose{i}_zdir"] = cam[5][0].numpy()
+        meta["poses"].append(dict(S=S, yaw=yaw, pitch=pitch))
+    with quiet():
+        ra = ref_import.make_reference_renderer(ns, "AFHQCat", 4)
+        ra.set_cam(ra.cam_fov, 6, 6)
+    cam = ra.sample_cam_poses(2, 0.0, 0.0, 0.0, 0.0, False, given_yaws=torch.tensor([[0.2], [-0.4]]),
+                              given_pitches=torch.tensor([[0.1], [0.3]]))
+    out["afhq_c2w"] = cam[2].numpy()
+    out["afhq_ray"] = torch.cat(cam[3]).numpy()
+    # RNG-consuming pose sampling (truncated_gaussian / uniform / gaussian; random + deterministic sweeps)
+    with quiet():
+        r.set_cam(r.cam_fov, 4, 4)
+    for j, (method, rnd, B) in enumerate([("truncated_gaussian", True, 5), ("uniform", True, 3),
+                                         ("gaussian", True, 3), ("truncated_gaussian", False, 4)]):
+        r.cam_sample_method = method
+        torch.manual_seed(100 + j)
+        cam = r.sample_cam_poses(B, 0.05, 0.289, -0.02, 0.127, rnd)
+        out[f"sample{j}_yaws"] = cam[0].numpy()
+        out[f"sample{j}_pitches"] = cam[1].numpy()
+        out[f"sample{j}_c2w"] = cam[2].numpy()
+        out[f"sample{j}_after"] = torch.rand(2).numpy()  # RNG stream position after the call
+        meta.setdefault("samples", []).append(dict(method=method, random=rnd, B=B, seed=100 + j))
+    # video-style call: std 0 through the truncated_gaussian sampler (render_video.py:236-237 pattern)
+    r.cam_sample_method = "truncated_gaussian"
+    torch.manual_seed(200)
+    cam = r.sample_cam_poses(1, 0.25, 0.0, 0.0, 0.0, True)
+    out["video_yaws"] = cam[0].numpy()
+    out["video_c2w"] = cam[2].numpy()
+    out["video_after"] = torch.rand(2).numpy()
+    np.savez(os.path.join(OUT, "geometry.npz"), meta=json.dumps(meta), **out)
+    print("wrote geometry", len(out), "arrays")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)
+    ns = ref_import.import_reference()
+    for case in RENDER_CASES:
+        run_render_case(ns, case)
+    run_multiview_case(ns)
+    run_geometry(ns)
+    with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
+        f.write("Generated by oracle/make_golden.py from the reference at /root/reference "
+                "(apple/ml-gmpi @ 2024_08_07), CPU fp32, torch %s, numpy %s.\n" % (torch.__version__, np.__version__))
+
+
+if __name__ == "__main__":
+    main()
