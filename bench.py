@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the MPI render hot path on MI355X (one JSON line on rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg3_f32|cfg4|cfg5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): Mpix*planes/s = views*H*W*D / t / 1e6 (whole job, all GPUs), plus views/s and
+the fraction of the HBM roofline.  A "step" = ONE pass of the hot path over one batch of views
+(one fused kernel launch: warp + composite + depth + asserts), inputs resident in HBM.
+
+Default workload = BASELINE.json configs[2] ("FFHQ1024-shaped: 1024x1024, 96 planes, batch 4 views,
+bf16", the configuration the north-star target is quoted on); each rank renders its own batch
+(independent views/seeds, no data-path collective -> "weak" scaling).  The final frame all_gather
+(RCCL) is timed separately (`gather_ms`), outside the K timed steps.
+
+roofline.achieved = ALGORITHMIC bytes per launch / average kernel duration (HIP events around every
+launch on the launch stream).  Algorithmic bytes:
+    N*D*4*Ht*Wt*s_in  +  N*H*W*12 (ray_dir)  +  N*H*W*4*(3+1[+1]) (outputs)
+cpu_baseline = the CPU oracle (oracle/mpi_oracle.c, OpenMP build, kind "port") timed on this box's
+host cores on a bounded sample of the same workload -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
+
+WORKLOADS = {
+    # name: (preset, S (=H=W=Ht=Wt), D, views per GPU, storage dtype, want_T, description)
+    "cfg2": ("FFHQ", 256, 96, 8, "f32", False, "FFHQ256-shaped: 256x256, 96 planes, batch 8 views, fp32"),
+    "cfg3": ("FFHQ", 1024, 96, 4, "bf16", False, "FFHQ1024-shaped: 1024x1024, 96 planes, batch 4 views, bf16 storage"),
+    "cfg3_f32": ("FFHQ", 1024, 96, 4, "f32", False, "FFHQ1024-shaped: 1024x1024, 96 planes, batch 4 views, fp32 storage"),
+    "cfg4": ("FFHQ", 512, 96, 8, "f32", False, "FFHQ512-shaped: 512x512, 96 planes, 8 camera-path views of ONE MPI per GPU"),
+    "cfg5": ("MetFaces", 1024, 256, 4, "f32", True, "MetFaces-shaped: 1024x1024, 256 planes + depth/transmittance, 4 seeds per GPU"),
+}
+
+
+def algorithmic_bytes(n_views, D, S, s_in, want_T):
+    return n_views * D * 4 * S * S * s_in + n_views * S * S * 12 + n_views * S * S * 4 * (4 + (1 if want_T else 0))
+
+
+def cpu_baseline(preset, S, D, dtype, budget_s=20.0):
+    """Oracle (OpenMP) on ONE view of the workload shape, repeated until ~budget_s of CPU wall time."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from ml_gmpi_amd.renderer import MPIRenderer, PRESETS
+
+    oracle.build()
+    kw = dict(PRESETS[preset])
+    kw.update(n_mpi_planes=D, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse",
+              cam_sample_method="truncated_gaussian", mpi_align_corners=True, use_confined_volume=True,
+              device=torch.device("cpu"))
+    r = MPIRenderer(**kw)
+    r.set_cam(r.cam_fov, S, S)
+    torch.manual_seed(0)
+    cam = r.sample_cam_poses(1, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    rgba = torch.rand((1, D, 4, S, S))
+    if dtype == "bf16":
+        rgba = rgba.to(torch.bfloat16).float()
+    dhw = r.static_mpi_plane_dhws.reshape(1, -1, 3)
+    args = (rgba.numpy(), dhw.numpy(), cam[3][0].numpy(), cam[4][0].numpy(), cam[5][0].numpy())
+    oracle.render(*args, threads=True)  # warm-up (page-in)
+    reps, t0 = 0, time.perf_counter()
+    best = float("inf")
+    while True:
+        t1 = time.perf_counter()
+        oracle.render(*args, threads=True)
+        best = min(best, time.perf_counter() - t1)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 20:
+            break
+    return dict(value=round(S * S * D / best / 1e6, 2), unit="Mpix*planes/s", cores=oracle.num_threads(True),
+                kind="port", sample=f"1 view {S}x{S}x{D} ({dtype} values), best of {reps} runs of oracle/mpi_oracle.c (OpenMP)",
+                views_per_s=round(1.0 / best, 4))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", default="auto", choices=["auto", "gather", "lds"])
+    ap.add_argument("--strict", action="store_true", help="strict-order arithmetic (bit-identical to the oracle)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    import ml_gmpi_amd
+    from ml_gmpi_amd import _lib
+
+    preset, S, D, n_views, dtype, want_T, desc = WORKLOADS[a.workload]
+    r = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=a.variant, strict_order=a.strict,
+                                  on_out_of_plane="raise")
+    r.set_cam(r.cam_fov, S, S)
+    # ---- synthetic inputs, resident in HBM --------------------------------------------------------
+    n_mpis = 1 if a.workload == "cfg4" else n_views
+    g = torch.Generator(device=dev).manual_seed(1000 * 3 + rank)
+    rgba = torch.empty((n_mpis, D, 4, S, S), device=dev, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+    for i in range(n_mpis):  # per-MPI fill keeps the transient fp32 copy small
+        rgba[i] = torch.rand((D, 4, S, S), device=dev, generator=g).to(rgba.dtype)
+    rgba[:, -1, 3] = 1.0  # background_alpha_full (networks_cond_on_pos_enc.py:1307-1310)
+    torch.manual_seed(3 + rank)
+    if a.workload == "cfg4":  # video path: yaw sweep, pitch 0 (render_video.py:236-237), this rank's 8 of 64 views
+        import numpy as np
+        yaw = np.linspace(0.5, -0.5, 8 * world)[rank::world]
+        cam = r.sample_cam_poses(n_views, 0, 0, 0, 0, False, given_yaws=torch.tensor(yaw, dtype=torch.float32).view(-1, 1),
+                                 given_pitches=torch.zeros(n_views, 1))
+    else:
+        cam = r.sample_cam_poses(n_views, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    ray, eye, zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+    dhw = r._dhw_on_device().expand(n_mpis, -1, -1).contiguous()
+    vpm = n_views if a.workload == "cfg4" else 1
+    out = dict(color=torch.empty((n_views, 3, S, S), device=dev), depth=torch.empty((n_views, 1, S, S), device=dev))
+    if want_T:
+        out["T"] = torch.empty((n_views, 1, S, S), device=dev)
+    status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+
+    def step():
+        r.mpi.render_views(rgba, dhw, ray, eye, zd, views_per_mpi=vpm, check_last_plane=True, out_pm1=True,
+                           want_transmittance=want_T, status=status, defer_status=True, out=out)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            step()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            ev[i][0].record()  # same stream the kernel is launched on (torch's current stream)
+            step()
+            ev[i][1].record()
+        fence()
+        elapsed = time.perf_counter() - t0
+        r.mpi.raise_on_status(status)  # asserts of all steps, one read-back
+        # end-to-end MPIRenderer.render(): pose sampling on the host + rays + launch + status sync
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        e2e_reps = 3
+        for _ in range(e2e_reps):
+            r.render(rgba, S, S, views_per_mpi=vpm)
+        torch.cuda.synchronize(dev)
+        e2e_ms = (time.perf_counter() - t1) / e2e_reps * 1e3
+        # final gather of the finished frames (the only collective of the job)
+        gather_ms = None
+        if world > 1:
+            frames = torch.cat([out["color"], out["depth"]] + ([out["T"]] if want_T else []), dim=1)
+            buf = torch.empty((world,) + tuple(frames.shape), device=dev)
+            fence()
+            tg = time.perf_counter()
+            dist.all_gather_into_tensor(buf.view(-1, *frames.shape[1:]), frames)
+            fence()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+
+    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+    t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        units_per_step = n_views * S * S * D * world  # pixel*planes, all ranks
+        value = units_per_step * a.steps / elapsed / 1e6
+        s_in = 2 if dtype == "bf16" else 4
+        abytes = algorithmic_bytes(n_views, D, S, s_in, want_T)
+        achieved = abytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes per launch, if measured
+        if os.path.isfile(prof):
+            try:
+                traffic = json.load(open(prof)).get(a.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mpix*planes/s", "value": round(value, 1), "unit": "Mpix*planes/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "name": a.workload, "views_per_gpu": n_views, "H": S, "W": S, "planes": D,
+                       "rgba_storage": dtype, "variant": a.variant, "strict_order": a.strict,
+                       "outputs": "rgb+depth" + ("+transmittance" if want_T else ""), "parallelism": f"views sharded x{world}"},
+            "views_per_s": round(n_views * world * a.steps / elapsed, 2),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": abytes},
+            "e2e_render_ms": round(e2e_ms, 3), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(preset, S, D, dtype, a.cpu_budget)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

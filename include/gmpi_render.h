@@ -1,0 +1,147 @@
+/*
+ * gmpi_render.h -- C ABI of the MI355X-native multiplane-image (MPI) renderer.
+ *
+ * This is the drop-in boundary for ONE path of apple/ml-gmpi: the gmpi/core renderer
+ *   homography()          gmpi/core/mpi.py:26-153     (ray/plane intersection + F.grid_sample)
+ *   MPI.forward()         gmpi/core/mpi.py:308-436    (front-to-back over-compositing, depth)
+ *   MPIRenderer.render()  gmpi/core/mpi_renderer.py:387-469 (range asserts, [0,1] -> [-1,1])
+ * The reference has no native entry point for this path (its only native code is the
+ * generator's bias_act/upfirdn2d pybind plugins, gmpi/models/torch_utils/ops/bias_act.cpp:94-97,
+ * whose convention -- one POD parameter struct, launch on the caller's stream -- is mirrored
+ * here).  Everything below is plain C: pointers, sizes, no torch types.  A Python host binds it
+ * with ctypes (ml-gmpi_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or
+ *     frees device memory and never synchronises the stream;
+ *   - every entry point returns 0 or a negative GMPI_E_* code; it never throws and never exits
+ *     (the reference's `sys.exit(1)` on a ray leaving the last plane, mpi.py:105-128, becomes a
+ *     status bit the host turns into the same diagnostics);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - re-entrant, no global state.
+ */
+#ifndef GMPI_RENDER_H
+#define GMPI_RENDER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMPI_ABI_VERSION 1
+
+/* storage type of the RGBA volume; arithmetic is always fp32 (mpi_renderer.py:446 `.float()`) */
+enum { GMPI_DTYPE_F32 = 0, GMPI_DTYPE_BF16 = 1, GMPI_DTYPE_F16 = 2 };
+
+/* GmpiRenderParams.flags */
+enum {
+    GMPI_FLAG_ALIGN_CORNERS = 1 << 0,    /* MPI(align_corners=...)            mpi.py:157-159, 86-99    */
+    GMPI_FLAG_OUT_PM1 = 1 << 1,          /* write 2*C-1 instead of C          mpi_renderer.py:467      */
+    GMPI_FLAG_CHECK_LAST_PLANE = 1 << 2, /* assert_not_out_of_last_plane      mpi.py:381-395, 103-109  */
+    GMPI_FLAG_CHECK_RANGE = 1 << 3,      /* rgba/alpha in [0,1] on the texels the render touches
+                                            (mpi.py:185-187, mpi_renderer.py:447-449); the exhaustive
+                                            variant is gmpi_rgba_range_check_launch                   */
+    GMPI_FLAG_STRICT_ORDER = 1 << 4,     /* one rounding per reference op everywhere (bit-identical to
+                                            oracle/mpi_oracle.c); default lets the blend use FMA       */
+};
+
+/* bits of status[0] (OR-accumulated across launches until the caller clears the word) */
+enum {
+    GMPI_STATUS_OUT_OF_LAST_PLANE = 1u << 0, /* mpi.py:106-109 would have failed                      */
+    GMPI_STATUS_RGBA_RANGE = 1u << 1,        /* mpi.py:185-187 / mpi_renderer.py:447-449              */
+    GMPI_STATUS_CAMERA_BEHIND_PLANE = 1u << 2 /* mpi.py:70-72 "Camera must be placed closer..."      */
+};
+#define GMPI_STATUS_WORDS 4
+
+/* kernel selection (GmpiRenderParams.variant) */
+enum {
+    GMPI_VARIANT_AUTO = 0,
+    GMPI_VARIANT_GATHER = 1, /* one pixel per lane, taps straight from global memory (any shape/stride) */
+    GMPI_VARIANT_LDS = 2     /* pixel tiles, texel boxes staged through LDS with 16-byte row loads      */
+};
+
+enum {
+    GMPI_OK = 0,
+    GMPI_E_NULL = -1,        /* required pointer is NULL                      */
+    GMPI_E_SHAPE = -2,       /* non-positive / inconsistent extent            */
+    GMPI_E_DTYPE = -3,       /* unknown rgba_dtype                            */
+    GMPI_E_STRIDE = -4,      /* innermost rgba stride != 1 or negative stride */
+    GMPI_E_ABI = -5,         /* struct_size does not match this library       */
+    GMPI_E_VARIANT = -6,     /* requested kernel variant cannot run this shape */
+    GMPI_E_LAUNCH = -100     /* -100 - hipError_t of the failed launch        */
+};
+
+/*
+ * One render call = MPI.forward (mpi.py:308-436) [+ the epilogue of MPIRenderer.render].
+ *
+ *   N views, M multiplane images, D planes per MPI (plane 0 nearest, mpi.py:413).
+ *   View n samples MPI  view_to_mpi[n]  (or n / views_per_mpi when view_to_mpi is NULL); this
+ *   replaces the reference's expand+cat of the volume per view (mpi.py:331-346) -- the volume is
+ *   never replicated.
+ */
+typedef struct GmpiRenderParams {
+    uint32_t struct_size; /* = sizeof(GmpiRenderParams) */
+    uint32_t flags;       /* GMPI_FLAG_*                */
+    int32_t variant;      /* GMPI_VARIANT_*             */
+    int32_t rgba_dtype;   /* GMPI_DTYPE_*               */
+
+    int32_t N, M, D;         /* views, MPIs, planes                                   */
+    int32_t Ht, Wt;          /* texture height/width (texels)                          */
+    int32_t H, W;            /* rendered image height/width (pixels)                   */
+    int32_t views_per_mpi;   /* used when view_to_mpi == NULL (>=1)                    */
+
+    const void *rgba;        /* [M, D, 4, Ht, Wt] planar RGBA in [0,1]                 */
+    int64_t rgba_stride[5];  /* element strides; [4] must be 1; 0 allowed on [0] (expand) */
+    const int32_t *view_to_mpi; /* [N] or NULL                                          */
+    const float *dhw;        /* [M, D, 3] (distance, height, width), contiguous         */
+    const float *ray_dir;    /* [N, 3, H, W] unit ray directions, contiguous            */
+    const float *eye_pos;    /* [N, 3]                                                  */
+    const float *z_dir;      /* [N, 3] optical axis                                     */
+
+    float *rgb_out;          /* [N, 3, H, W]   colour, [0,1] (or [-1,1] with OUT_PM1)   */
+    float *depth_out;        /* [N, 1, H, W]   expected depth (mpi.py:434)              */
+    float *transmittance_out;/* [N, 1, H, W] or NULL: prod_k (1-a_k+1e-10) -- the cumprod
+                                element the reference slices off at mpi.py:423            */
+    uint32_t *status;        /* [GMPI_STATUS_WORDS] or NULL; word 0 is OR-ed with GMPI_STATUS_* */
+} GmpiRenderParams;
+
+/* Enqueue the fused render on `stream`.  Replaces MPI.forward (mpi.py:308-436). */
+int gmpi_mpi_render_launch(const GmpiRenderParams *params, void *stream);
+
+/*
+ * Diagnostics for a tripped GMPI_STATUS_OUT_OF_LAST_PLANE: min_u, max_u, min_v, max_v of the
+ * normalised grid on the LAST plane per view (what mpi.py:106-109 print).  uv_minmax: [N,4] float.
+ * Uses N, M, D, H, W, flags(ALIGN_CORNERS), view_to_mpi/views_per_mpi, dhw, ray_dir, eye_pos.
+ */
+int gmpi_last_plane_uv_minmax_launch(const GmpiRenderParams *params, float *uv_minmax, void *stream);
+
+/*
+ * Exhaustive range check over `count` contiguous elements (the reference's two full min/max
+ * passes, mpi.py:185-187 and mpi_renderer.py:447-449): ORs GMPI_STATUS_RGBA_RANGE into status[0]
+ * when any value is outside [0,1] or NaN.
+ */
+int gmpi_rgba_range_check_launch(const void *rgba, int32_t rgba_dtype, int64_t count, uint32_t *status,
+                                 void *stream);
+
+/*
+ * Per-view epilogue of the reference's drivers (render_video.py:118-126, prepare_fake_data.py):
+ *   img8  [N,H,W,3] = uint8( ((rgb_pm1 + 1) / 2) * 255 )           (C truncation, as numpy astype)
+ *   dep8  [N,H,W,1] = uint8( clip((depth - near) / (far - near), 0, 1) * 255 )
+ * rgb is the OUT_PM1 colour [N,3,H,W]; either output may be NULL.  near/far are the Python floats
+ * `ray_start`/`ray_end`; as in numpy the subtraction uses float32(near) and the division uses
+ * float32(far - near) (difference taken in double).
+ */
+int gmpi_frames_to_uint8_launch(const float *rgb_pm1, const float *depth, int32_t N, int32_t H, int32_t W,
+                                double depth_near, double depth_far, uint8_t *img8, uint8_t *dep8, void *stream);
+
+/* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
+ * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height.  Unknown -> -1.      */
+int gmpi_query(int32_t what);
+
+const char *gmpi_version_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMPI_RENDER_H */

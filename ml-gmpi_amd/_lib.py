@@ -1,0 +1,121 @@
+"""ctypes binding of the C-ABI library `libgmpi_render.so` (include/gmpi_render.h).
+
+The HIP library IS the product: there is no CPU or PyTorch fallback.  If the shared object is
+missing or does not export the ABI this header declares, loading fails loudly with instructions to
+build it (`python -c "import __graft_entry__ as g; g.build()"` or `make -C ml-gmpi_amd/csrc`).
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, "libgmpi_render.so")
+_LIB = None
+
+ABI_VERSION = 1
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+FLAG_ALIGN_CORNERS, FLAG_OUT_PM1, FLAG_CHECK_LAST_PLANE, FLAG_CHECK_RANGE, FLAG_STRICT_ORDER = 1, 2, 4, 8, 16
+STATUS_OUT_OF_LAST_PLANE, STATUS_RGBA_RANGE, STATUS_CAMERA_BEHIND_PLANE = 1, 2, 4
+STATUS_WORDS = 4
+VARIANT_AUTO, VARIANT_GATHER, VARIANT_LDS = 0, 1, 2
+VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS}
+
+EXPORTS = (
+    "gmpi_mpi_render_launch",
+    "gmpi_last_plane_uv_minmax_launch",
+    "gmpi_rgba_range_check_launch",
+    "gmpi_frames_to_uint8_launch",
+    "gmpi_query",
+    "gmpi_version_string",
+)
+
+_ERRORS = {
+    -1: "GMPI_E_NULL (required pointer is NULL)",
+    -2: "GMPI_E_SHAPE (non-positive or inconsistent extent)",
+    -3: "GMPI_E_DTYPE (unknown rgba dtype)",
+    -4: "GMPI_E_STRIDE (innermost rgba stride must be 1, strides non-negative)",
+    -5: "GMPI_E_ABI (GmpiRenderParams size mismatch between binding and library)",
+    -6: "GMPI_E_VARIANT (requested kernel variant cannot run this shape)",
+}
+
+
+class GmpiError(RuntimeError):
+    pass
+
+
+class GmpiRenderParams(ctypes.Structure):
+    """Field-for-field mirror of `struct GmpiRenderParams` in include/gmpi_render.h."""
+    _fields_ = [
+        ("struct_size", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+        ("variant", ctypes.c_int32), ("rgba_dtype", ctypes.c_int32),
+        ("N", ctypes.c_int32), ("M", ctypes.c_int32), ("D", ctypes.c_int32),
+        ("Ht", ctypes.c_int32), ("Wt", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("views_per_mpi", ctypes.c_int32),
+        ("rgba", ctypes.c_void_p), ("rgba_stride", ctypes.c_int64 * 5),
+        ("view_to_mpi", ctypes.c_void_p), ("dhw", ctypes.c_void_p), ("ray_dir", ctypes.c_void_p),
+        ("eye_pos", ctypes.c_void_p), ("z_dir", ctypes.c_void_p),
+        ("rgb_out", ctypes.c_void_p), ("depth_out", ctypes.c_void_p), ("transmittance_out", ctypes.c_void_p),
+        ("status", ctypes.c_void_p),
+    ]
+
+
+def library_path() -> str:
+    return _SO
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (ml-gmpi_amd/csrc/Makefile). Returns the .so path."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j4"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0 or not os.path.isfile(_SO):
+        raise GmpiError("building libgmpi_render.so failed:\n" + res.stderr[-4000:])
+    return _SO
+
+
+def load_library():
+    """Load (once) and type the C ABI.  Raises GmpiError when the HIP library is not there."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.isfile(_SO):
+        raise GmpiError(
+            f"HIP extension not built: {_SO} is missing. This package has no CPU/PyTorch fallback. "
+            "Build it with `python -c \"import __graft_entry__ as g; g.build()\"` or `make -C ml-gmpi_amd/csrc`.")
+    import torch  # noqa: F401  -- load torch's ROCm runtime first so both sides share one libamdhip64
+    try:
+        lib = ctypes.CDLL(_SO)
+    except OSError as e:
+        raise GmpiError(f"could not load {_SO}: {e}") from e
+    missing = [s for s in EXPORTS if not hasattr(lib, s)]
+    if missing:
+        raise GmpiError(f"{_SO} does not export {missing}; rebuild it")
+    vp = ctypes.c_void_p
+    lib.gmpi_mpi_render_launch.restype = ctypes.c_int
+    lib.gmpi_mpi_render_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp]
+    lib.gmpi_last_plane_uv_minmax_launch.restype = ctypes.c_int
+    lib.gmpi_last_plane_uv_minmax_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp, vp]
+    lib.gmpi_rgba_range_check_launch.restype = ctypes.c_int
+    lib.gmpi_rgba_range_check_launch.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, vp, vp]
+    lib.gmpi_frames_to_uint8_launch.restype = ctypes.c_int
+    lib.gmpi_frames_to_uint8_launch.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_double, ctypes.c_double, vp, vp, vp]
+    lib.gmpi_query.restype = ctypes.c_int
+    lib.gmpi_query.argtypes = [ctypes.c_int32]
+    lib.gmpi_version_string.restype = ctypes.c_char_p
+    lib.gmpi_version_string.argtypes = []
+    if lib.gmpi_query(0) != ABI_VERSION or lib.gmpi_query(1) != ctypes.sizeof(GmpiRenderParams):
+        raise GmpiError(f"ABI mismatch: library ABI {lib.gmpi_query(0)} / struct {lib.gmpi_query(1)} B, "
+                        f"binding ABI {ABI_VERSION} / struct {ctypes.sizeof(GmpiRenderParams)} B")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc <= -100:
+        raise GmpiError(f"{what}: HIP launch failed (hipError_t {-100 - rc})")
+    raise GmpiError(f"{what}: {_ERRORS.get(rc, rc)}")

@@ -1,0 +1,235 @@
+// gmpi_abi.hip -- the extern "C" entry points declared in include/gmpi_render.h, plus the small
+// auxiliary kernels (diagnostics, exhaustive range check, uint8 frame epilogue).
+#include "gmpi_device.hpp"
+
+#include "../../include/gmpi_render.h"
+
+namespace gmpi {
+
+hipError_t launch_gather(const KParams& p, int dtype, hipStream_t stream);  // render_gather.hip
+hipError_t launch_lds(const KParams& p, int dtype, hipStream_t stream);     // render_lds.hip
+bool lds_variant_supports(const KParams& p, int dtype);                     // render_lds.hip
+int lds_variant_query(int what);                                            // render_lds.hip
+
+// ---- min/max of the normalised grid on the last plane (mpi.py:103-109 diagnostics) --------------
+template <bool AC>
+__global__ __launch_bounds__(256) void last_plane_uv_kernel(const KParams p, float* __restrict__ uv) {
+    const int n = blockIdx.x;
+    const int m = p.view_to_mpi ? p.view_to_mpi[n] : n / p.views_per_mpi;
+    const float* dhw = p.dhw + (static_cast<int64_t>(m) * p.D + (p.D - 1)) * 3;
+    const float d = dhw[0], ph = dhw[1], pw = dhw[2];
+    const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
+    const float zdiff = d - ez;
+    const int64_t HW = static_cast<int64_t>(p.H) * p.W;
+    const float* rd = p.ray_dir + static_cast<int64_t>(n) * 3 * HW;
+    const float inf = __builtin_inff();
+    float mnu = inf, mxu = -inf, mnv = inf, mxv = -inf;
+    bool nan = false;
+    for (int64_t i = threadIdx.x; i < HW; i += blockDim.x) {
+        float ix, iy, s, u, v;
+        plane_coord<AC>(zdiff, ph, pw, ex, ey, rd[i], rd[HW + i], rd[2 * HW + i], 1.0f, 1.0f, ix, iy, s, u, v);
+        nan |= (u != u) || (v != v);
+        mnu = fminf(mnu, u), mxu = fmaxf(mxu, u), mnv = fminf(mnv, v), mxv = fmaxf(mxv, v);
+    }
+    __shared__ float red[4][256];
+    __shared__ int red_nan;
+    if (threadIdx.x == 0) red_nan = 0;
+    red[0][threadIdx.x] = mnu, red[1][threadIdx.x] = mxu, red[2][threadIdx.x] = mnv, red[3][threadIdx.x] = mxv;
+    __syncthreads();
+    if (nan) atomicOr(&red_nan, 1);
+    for (int o = 128; o > 0; o >>= 1) {
+        if (static_cast<int>(threadIdx.x) < o) {
+            red[0][threadIdx.x] = fminf(red[0][threadIdx.x], red[0][threadIdx.x + o]);
+            red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + o]);
+            red[2][threadIdx.x] = fminf(red[2][threadIdx.x], red[2][threadIdx.x + o]);
+            red[3][threadIdx.x] = fmaxf(red[3][threadIdx.x], red[3][threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) {
+        const float q = __builtin_nanf("");
+        uv[4 * n + threadIdx.x] = red_nan ? q : red[threadIdx.x][0];  // torch.min/max propagate NaN
+    }
+}
+
+// ---- exhaustive [0,1] check (the reference's full min/max passes) ----------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void range_check_kernel(const T* __restrict__ v, int64_t count, uint32_t* status) {
+    bool bad = false;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count; i += stride)
+        bad |= !in_unit(to_f32(v[i]));
+    report_status(status, bad ? 2u : 0u);
+}
+
+// 16-byte vectorised body for contiguous, aligned volumes
+template <typename T, int PER>
+__global__ __launch_bounds__(256) void range_check_vec_kernel(const uint4* __restrict__ v, int64_t nvec,
+                                                              uint32_t* status) {
+    bool bad = false;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const uint4 q = v[i];
+        const T* e = reinterpret_cast<const T*>(&q);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) bad |= !in_unit(to_f32(e[j]));
+    }
+    report_status(status, bad ? 2u : 0u);
+}
+
+// ---- driver epilogue: float frames -> uint8 (render_video.py:118-126) -------------------------------
+__global__ __launch_bounds__(256) void frames_to_uint8_kernel(const float* __restrict__ rgb, const float* __restrict__ dep,
+                                                              int64_t HW, int64_t total, float dnear, float span,
+                                                              uint8_t* __restrict__ img8, uint8_t* __restrict__ dep8) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;  // over N*H*W
+    if (i >= total) return;
+    const int64_t n = i / HW, q = i - n * HW;
+    if (img8) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = rgb[(n * 3 + c) * HW + q];
+            v = v + 1.0f;    // img = (img + 1) / 2.0
+            v = v / 2.0f;
+            v = v * 255.0f;  // (img * 255).astype(np.uint8): C truncation toward zero
+            // astype(uint8) of an out-of-range float is UB in numpy; compositing keeps v in [0,255], clamp for safety
+            v = fminf(fmaxf(v, 0.0f), 255.0f);
+            img8[i * 3 + c] = static_cast<uint8_t>(static_cast<int>(v));
+        }
+    }
+    if (dep8) {
+        float v = dep[i];
+        v = v - dnear;
+        v = v / span;
+        v = fminf(fmaxf(v, 0.0f), 1.0f);  // np.clip
+        v = v * 255.0f;
+        dep8[i] = static_cast<uint8_t>(static_cast<int>(v));
+    }
+}
+
+static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs) {
+    if (q == nullptr) return GMPI_E_NULL;
+    if (q->struct_size != sizeof(GmpiRenderParams)) return GMPI_E_ABI;
+    if (q->N < 0 || q->M <= 0 || q->D <= 0 || q->Ht <= 0 || q->Wt <= 0 || q->H <= 0 || q->W <= 0) return GMPI_E_SHAPE;
+    if (q->view_to_mpi == nullptr) {
+        if (q->views_per_mpi < 1) return GMPI_E_SHAPE;
+        if (q->N > static_cast<int64_t>(q->M) * q->views_per_mpi) return GMPI_E_SHAPE;
+    }
+    if (q->dhw == nullptr || q->ray_dir == nullptr || q->eye_pos == nullptr) return GMPI_E_NULL;
+    if (need_outputs) {
+        if (q->rgba == nullptr || q->z_dir == nullptr || q->rgb_out == nullptr || q->depth_out == nullptr) return GMPI_E_NULL;
+        if (q->rgba_dtype < GMPI_DTYPE_F32 || q->rgba_dtype > GMPI_DTYPE_F16) return GMPI_E_DTYPE;
+        if (q->rgba_stride[4] != 1) return GMPI_E_STRIDE;
+        for (int i = 0; i < 4; ++i)
+            if (q->rgba_stride[i] < 0) return GMPI_E_STRIDE;
+        if (q->rgba_stride[3] < q->Wt || q->rgba_stride[2] == 0 || q->rgba_stride[1] == 0) return GMPI_E_STRIDE;
+    }
+    p.rgba = q->rgba;
+    p.view_to_mpi = q->view_to_mpi;
+    p.dhw = q->dhw;
+    p.ray_dir = q->ray_dir;
+    p.eye_pos = q->eye_pos;
+    p.z_dir = q->z_dir;
+    p.rgb_out = q->rgb_out;
+    p.depth_out = q->depth_out;
+    p.T_out = q->transmittance_out;
+    p.status = q->status;
+    p.s_mpi = q->rgba_stride[0];
+    p.s_plane = q->rgba_stride[1];
+    p.s_chan = q->rgba_stride[2];
+    p.s_row = q->rgba_stride[3];
+    p.N = q->N, p.M = q->M, p.D = q->D, p.Ht = q->Ht, p.Wt = q->Wt, p.H = q->H, p.W = q->W;
+    p.views_per_mpi = q->view_to_mpi ? 1 : q->views_per_mpi;
+    p.flags = q->flags;
+    return GMPI_OK;
+}
+
+static int hip_rc(hipError_t e) { return e == hipSuccess ? GMPI_OK : GMPI_E_LAUNCH - static_cast<int>(e); }
+
+}  // namespace gmpi
+
+using namespace gmpi;
+
+extern "C" {
+
+int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
+    KParams p;
+    const int rc = to_kparams(params, p, true);
+    if (rc != GMPI_OK) return rc;
+    if (p.N == 0) return GMPI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int variant = params->variant;
+    if (variant == GMPI_VARIANT_AUTO) variant = lds_variant_supports(p, params->rgba_dtype) ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
+    if (variant == GMPI_VARIANT_GATHER) return hip_rc(launch_gather(p, params->rgba_dtype, st));
+    if (variant == GMPI_VARIANT_LDS) {
+        if (!lds_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
+        return hip_rc(launch_lds(p, params->rgba_dtype, st));
+    }
+    return GMPI_E_VARIANT;
+}
+
+int gmpi_last_plane_uv_minmax_launch(const GmpiRenderParams* params, float* uv_minmax, void* stream) {
+    KParams p;
+    const int rc = to_kparams(params, p, false);
+    if (rc != GMPI_OK) return rc;
+    if (uv_minmax == nullptr) return GMPI_E_NULL;
+    if (p.N == 0) return GMPI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p.flags & GMPI_FLAG_ALIGN_CORNERS) hipLaunchKernelGGL(last_plane_uv_kernel<true>, dim3(p.N), dim3(256), 0, st, p, uv_minmax);
+    else hipLaunchKernelGGL(last_plane_uv_kernel<false>, dim3(p.N), dim3(256), 0, st, p, uv_minmax);
+    return hip_rc(hipGetLastError());
+}
+
+int gmpi_rgba_range_check_launch(const void* rgba, int32_t rgba_dtype, int64_t count, uint32_t* status, void* stream) {
+    if (rgba == nullptr || status == nullptr) return GMPI_E_NULL;
+    if (count < 0) return GMPI_E_SHAPE;
+    if (rgba_dtype < GMPI_DTYPE_F32 || rgba_dtype > GMPI_DTYPE_F16) return GMPI_E_DTYPE;
+    if (count == 0) return GMPI_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int esz = rgba_dtype == GMPI_DTYPE_F32 ? 4 : 2;
+    const int per = 16 / esz;
+    const bool aligned = (reinterpret_cast<uintptr_t>(rgba) % 16) == 0;
+    const int64_t nvec = aligned ? count / per : 0;
+    const int64_t tail = count - nvec * per;
+    if (nvec > 0) {
+        const int blocks = static_cast<int>(std::min<int64_t>((nvec + 255) / 256, 256 * 8));
+        const uint4* v = static_cast<const uint4*>(rgba);
+        if (rgba_dtype == GMPI_DTYPE_F32) hipLaunchKernelGGL((range_check_vec_kernel<float, 4>), dim3(blocks), dim3(256), 0, st, v, nvec, status);
+        else if (rgba_dtype == GMPI_DTYPE_BF16) hipLaunchKernelGGL((range_check_vec_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, st, v, nvec, status);
+        else hipLaunchKernelGGL((range_check_vec_kernel<f16_t, 8>), dim3(blocks), dim3(256), 0, st, v, nvec, status);
+    }
+    if (tail > 0) {
+        const char* base = static_cast<const char*>(rgba) + nvec * 16;
+        const int blocks = static_cast<int>(std::min<int64_t>((tail + 255) / 256, 256 * 8));
+        if (rgba_dtype == GMPI_DTYPE_F32) hipLaunchKernelGGL(range_check_kernel<float>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(base), tail, status);
+        else if (rgba_dtype == GMPI_DTYPE_BF16) hipLaunchKernelGGL(range_check_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(base), tail, status);
+        else hipLaunchKernelGGL(range_check_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f16_t*>(base), tail, status);
+    }
+    return hip_rc(hipGetLastError());
+}
+
+int gmpi_frames_to_uint8_launch(const float* rgb_pm1, const float* depth, int32_t N, int32_t H, int32_t W, double depth_near,
+                                double depth_far, uint8_t* img8, uint8_t* dep8, void* stream) {
+    if (N < 0 || H <= 0 || W <= 0) return GMPI_E_SHAPE;
+    if ((img8 && !rgb_pm1) || (dep8 && !depth)) return GMPI_E_NULL;
+    if (N == 0 || (!img8 && !dep8)) return GMPI_OK;
+    const int64_t HW = static_cast<int64_t>(H) * W, total = HW * N;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(frames_to_uint8_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       rgb_pm1, depth, HW, total, static_cast<float>(depth_near), static_cast<float>(depth_far - depth_near), img8,
+                       dep8);
+    return hip_rc(hipGetLastError());
+}
+
+int gmpi_query(int32_t what) {
+    switch (what) {
+        case 0: return GMPI_ABI_VERSION;
+        case 1: return static_cast<int>(sizeof(GmpiRenderParams));
+        case 2: return 950;
+        case 3: case 4: case 5: return lds_variant_query(what);
+        default: return -1;
+    }
+}
+
+const char* gmpi_version_string(void) { return "ml-gmpi_amd 0.1 (gfx950, ABI 1)"; }
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+// gmpi_device.hpp -- device-side arithmetic shared by the render kernels (gfx950 / CDNA4 only).
+//
+// The coordinate chain below must reproduce the reference's fp32 arithmetic EXACTLY
+// (gmpi/core/mpi.py:74-99 followed by ATen's grid_sampler unnormalize): a 1-ulp difference in
+// ray/plane intersection moves the sample position by up to 4e-4 texel at 1024^2 and the output by
+// up to 5e-4 on white-noise textures (hard part 1).  Hence:
+//   * this translation unit is compiled with -ffp-contract=off (and the pragma below): a*b+c is
+//     v_mul_f32 + v_add_f32, never v_fma_f32, unless __builtin_fmaf is written out;
+//   * a/b is the correctly rounded IEEE division (hipcc default
+//     -fhip-fp32-correctly-rounded-divide-sqrt; never -ffast-math);
+//   * fp32 denormals are on (gfx9 default).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace gmpi {
+
+constexpr float kNarrowScale = 0.95f;  // mpi.py:23 ALIGN_CORNERS_FALSE_NARROW_SCALE
+
+// Kernel-side view of GmpiRenderParams (include/gmpi_render.h), passed by value.
+struct KParams {
+    const void* rgba;
+    const int32_t* view_to_mpi;
+    const float* dhw;
+    const float* ray_dir;
+    const float* eye_pos;
+    const float* z_dir;
+    float* rgb_out;
+    float* depth_out;
+    float* T_out;
+    uint32_t* status;
+    int64_t s_mpi, s_plane, s_chan, s_row;  // element strides of rgba [M,D,4,Ht,Wt] (col stride 1)
+    int32_t N, M, D, Ht, Wt, H, W, views_per_mpi;
+    uint32_t flags;
+};
+
+// ---- texel fetch: storage type -> fp32 (exact upcast, mpi_renderer.py:446) -----------------------
+struct bf16_t { uint16_t bits; };
+struct f16_t { _Float16 v; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float(static_cast<uint32_t>(v.bits) << 16); }
+__device__ __forceinline__ float to_f32(f16_t v) { return static_cast<float>(v.v); }
+
+// ---- ray/plane intersection -> unnormalised texture coordinates --------------------------------
+// One rounding per line, in the reference's order.
+//   zdiff = d - eye_z                (mpi.py:74)   computed by the caller (wave-uniform)
+//   s     = zdiff / ray_z            (mpi.py:76)
+//   x     = eye_x + ray_x * s        (mpi.py:79)
+//   u     = (2 x) / w                (mpi.py:90)   2*x is exact
+//   AC:   ix = (u + 1) * ((Wt-1)/2)  == ((u+1)/2)*(Wt-1) as a real number -> same single rounding
+//   !AC:  u *= 0.95 if -1<=u<=1 (mpi.py:98-99); ix = ((u+1)*Wt - 1)/2   (GridSampler.h:27-35)
+template <bool AC>
+__device__ __forceinline__ void plane_coord(float zdiff, float ph, float pw, float ex, float ey, float rx, float ry,
+                                            float rz, float cx, float cy, float& ix, float& iy, float& s, float& u,
+                                            float& v) {
+    s = zdiff / rz;
+    const float tx = rx * s;
+    const float ty = ry * s;
+    const float x = ex + tx;
+    const float y = ey + ty;
+    const float x2 = 2.0f * x;
+    const float y2 = 2.0f * y;
+    u = x2 / pw;
+    v = y2 / ph;
+    if (AC) {
+        const float u1 = u + 1.0f;
+        const float v1 = v + 1.0f;
+        ix = u1 * cx;  // cx = (Wt-1)/2
+        iy = v1 * cy;  // cy = (Ht-1)/2
+    } else {
+        if (v >= -1.0f && v <= 1.0f) v = v * kNarrowScale;
+        if (u >= -1.0f && u <= 1.0f) u = u * kNarrowScale;
+        const float u1 = u + 1.0f;
+        const float v1 = v + 1.0f;
+        const float ux = u1 * cx;  // cx = Wt
+        const float vy = v1 * cy;  // cy = Ht
+        const float uxm = ux - 1.0f;
+        const float vym = vy - 1.0f;
+        ix = uxm * 0.5f;
+        iy = vym * 0.5f;
+    }
+}
+
+// Bilinear footprint: integer corner (clamped so that NaN / huge coordinates stay out of range) and
+// the four weights nw, ne, sw, se in ATen's order.
+struct Footprint {
+    int x0, y0;
+    float nw, ne, sw, se;
+};
+
+__device__ __forceinline__ Footprint footprint(float ix, float iy, int Ht, int Wt) {
+    Footprint f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const float fx1 = fx0 + 1.0f, fy1 = fy0 + 1.0f;
+    const float wx1 = ix - fx0, wx0 = fx1 - ix;
+    const float wy1 = iy - fy0, wy0 = fy1 - iy;
+    f.nw = wx0 * wy0;
+    f.ne = wx1 * wy0;
+    f.sw = wx0 * wy1;
+    f.se = wx1 * wy1;
+    f.x0 = (fx0 >= -2.0f && fx0 <= static_cast<float>(Wt)) ? static_cast<int>(fx0) : -2;
+    f.y0 = (fy0 >= -2.0f && fy0 <= static_cast<float>(Ht)) ? static_cast<int>(fy0) : -2;
+    return f;
+}
+
+// Composite state per pixel (mpi.py:421-434): T = running cumprod, C/Z the weighted sums.
+struct Accum {
+    float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f, z = 0.0f;
+};
+
+// STRICT: exactly the oracle's op sequence.  Otherwise the blend uses FMA (fewer roundings; the
+// difference is below 1e-6, everything after ix/iy is benign -- SURVEY.md section 7).
+template <bool STRICT>
+__device__ __forceinline__ float bilerp(float t_nw, float t_ne, float t_sw, float t_se, const Footprint& f) {
+    if (STRICT) {
+        float acc = t_nw * f.nw;
+        acc = acc + t_ne * f.ne;
+        acc = acc + t_sw * f.sw;
+        acc = acc + t_se * f.se;
+        return acc;
+    } else {
+        float acc = t_nw * f.nw;
+        acc = __builtin_fmaf(t_ne, f.ne, acc);
+        acc = __builtin_fmaf(t_sw, f.sw, acc);
+        acc = __builtin_fmaf(t_se, f.se, acc);
+        return acc;
+    }
+}
+
+template <bool STRICT>
+__device__ __forceinline__ void blend(Accum& A, float r, float g, float b, float a, float s, float dot) {
+    if (STRICT) {
+        const float dep = s * dot;          // mpi.py:150
+        const float disp = 1.0f / dep;      // mpi.py:151
+        const float depk = 1.0f / disp;     // mpi.py:411
+        const float w = a * A.T;            // mpi.py:423
+        A.r = A.r + w * r;                  // mpi.py:430
+        A.g = A.g + w * g;
+        A.b = A.b + w * b;
+        A.z = A.z + w * depk;               // mpi.py:434
+        float om = 1.0f - a;                // mpi.py:421
+        om = om + 1e-10f;
+        A.T = A.T * om;
+    } else {
+        const float depk = s * dot;  // 1/(1/x) == x to within 1 ulp; depth tolerance is 1e-5
+        const float w = a * A.T;
+        A.r = __builtin_fmaf(w, r, A.r);
+        A.g = __builtin_fmaf(w, g, A.g);
+        A.b = __builtin_fmaf(w, b, A.b);
+        A.z = __builtin_fmaf(w, depk, A.z);
+        float om = 1.0f - a;
+        om = om + 1e-10f;
+        A.T = A.T * om;
+    }
+}
+
+__device__ __forceinline__ bool in_unit(float v) { return v >= 0.0f && v <= 1.0f; }
+
+// OR a per-lane flag word into status[0] with at most one atomic per wave.
+__device__ __forceinline__ void report_status(uint32_t* status, uint32_t bad) {
+    if (status == nullptr) return;
+    if (__any(bad != 0u)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
+        if ((threadIdx.x + threadIdx.y * blockDim.x) % 64 == 0) atomicOr(status, bad);
+    }
+}
+
+}  // namespace gmpi

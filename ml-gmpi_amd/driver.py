@@ -1,0 +1,149 @@
+"""Per-view batch driver: many camera views of one or several MPIs, sharded over the GPUs of a node.
+
+Replaces the reference's host loops that call `render` once per view and copy every frame back
+(gmpi/eval/vis/render_video.py:95-130: one render + `.cpu()` per angle; prepare_fake_data.py:58-86;
+fid_evaluation.py:86-133: `img_counter = rank; img_counter += world_size`).  Here
+
+  * views are rendered in batches -- one launch per batch, the RGBA volume is indexed, never
+    replicated (`views_per_mpi`), and nothing is copied to the host inside the loop;
+  * the uint8 / depth-normalisation epilogue of render_video.py:118-126 runs on the device
+    (`gmpi_frames_to_uint8_launch`);
+  * across ranks the views are partitioned exactly like the reference's rank-strided counter, every
+    rank renders its shard independently (no data-path collective), and ONE all_gather of the
+    finished frames (RCCL over xGMI when the backend is "nccl") assembles the sequence.
+"""
+import ctypes
+from typing import Callable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def shard_views(n_views: int, rank: int, world_size: int, mode: str = "strided") -> List[int]:
+    """View indices rendered by `rank`.  "strided" = the reference's counter (rank, rank+W, ...);
+    "block" = contiguous blocks (better when consecutive views share an MPI)."""
+    assert 0 <= rank < world_size
+    if mode == "strided":
+        return list(range(rank, n_views, world_size))
+    if mode == "block":
+        per = (n_views + world_size - 1) // world_size
+        return list(range(min(rank * per, n_views), min((rank + 1) * per, n_views)))
+    raise ValueError(mode)
+
+
+def frames_to_uint8(rgb_pm1: torch.Tensor, depth: Optional[torch.Tensor], near: float, far: float):
+    """(img8 [N,H,W,3] uint8, dep8 [N,H,W,1] uint8 or None) on the device -- render_video.py:118-126."""
+    if not rgb_pm1.is_cuda:
+        raise _lib.GmpiError("frames_to_uint8 needs device tensors (no CPU path)")
+    lib = _lib.load_library()
+    rgb_pm1 = rgb_pm1.contiguous()
+    N, _, H, W = rgb_pm1.shape
+    img8 = torch.empty((N, H, W, 3), dtype=torch.uint8, device=rgb_pm1.device)
+    dep8 = None
+    if depth is not None:
+        depth = depth.contiguous()
+        dep8 = torch.empty((N, H, W, 1), dtype=torch.uint8, device=rgb_pm1.device)
+    with torch.cuda.device(rgb_pm1.device):
+        _lib.check(lib.gmpi_frames_to_uint8_launch(
+            rgb_pm1.data_ptr(), depth.data_ptr() if depth is not None else None, N, H, W, float(near), float(far),
+            img8.data_ptr(), dep8.data_ptr() if dep8 is not None else None,
+            torch.cuda.current_stream(rgb_pm1.device).cuda_stream), "gmpi_frames_to_uint8_launch")
+    return img8, dep8
+
+
+def gather_frames(local: torch.Tensor, indices: Sequence[int], n_views: int, group=None) -> torch.Tensor:
+    """all_gather of per-rank frame stacks [n_local, ...] into [n_views, ...] ordered by view index.
+
+    Shards may be ragged (n_views not divisible by the world size): every rank pads to the largest
+    shard so that a single fixed-size all_gather suffices; the index lists travel with the frames.
+    """
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        out = torch.empty((n_views,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        out[torch.as_tensor(list(indices), dtype=torch.long, device=local.device)] = local
+        return out
+    world = dist.get_world_size(group)
+    per = (n_views + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    idx = torch.full((per,), -1, dtype=torch.int64, device=local.device)
+    idx[: len(indices)] = torch.as_tensor(list(indices), dtype=torch.int64, device=local.device)
+    all_frames = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    all_idx = torch.empty((world * per,), dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(all_frames, pad, group=group)
+    dist.all_gather_into_tensor(all_idx, idx, group=group)
+    keep = all_idx >= 0
+    out = torch.empty((n_views,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    out[all_idx[keep]] = all_frames[keep]
+    return out
+
+
+def render_views_sharded(render_fn: Callable[[List[int]], torch.Tensor], n_views: int, rank: int = 0,
+                         world_size: int = 1, mode: str = "strided", gather: bool = True, group=None):
+    """Each rank renders `shard_views(...)` through `render_fn(indices) -> [n_local, C, H, W]`; with `gather`
+    the full [n_views, C, H, W] stack is returned on every rank, else (local_frames, indices)."""
+    indices = shard_views(n_views, rank, world_size, mode)
+    local = render_fn(indices)
+    assert local.shape[0] == len(indices), (local.shape, len(indices))
+    if not gather:
+        return local, indices
+    return gather_frames(local, indices, n_views, group=group)
+
+
+class ViewBatchDriver:
+    """Renders a camera path / a batch of seeds with an `MPIRenderer`, `batch` views per launch, device-resident."""
+
+    def __init__(self, renderer, batch: int = 8):
+        self.renderer = renderer
+        self.batch = int(batch)
+
+    @torch.no_grad()
+    def render_path(self, mpi_rgbas: torch.Tensor, render_size: int, yaws: Sequence[float],
+                    pitches: Sequence[float], indices: Optional[Sequence[int]] = None, to_uint8: bool = False,
+                    depth_range=None, want_transmittance: bool = False):
+        """Views `indices` (default all) of ONE MPI [1,D,4,Ht,Wt] along (yaws[i], pitches[i]) -- the loop of
+        render_video.py:95-130 (h_mean/v_mean = angle, std 0) as batched launches.
+
+        Returns dict(rgb [n,3,H,W] in [-1,1], depth [n,1,H,W][, T][, img8, dep8]) on the device.
+        """
+        r = self.renderer
+        assert mpi_rgbas.shape[0] == 1, "render_path draws many views of one MPI"
+        idx = list(range(len(yaws))) if indices is None else list(indices)
+        dev = mpi_rgbas.device
+        n = len(idx)
+        rgb = torch.empty((n, 3, render_size, render_size), dtype=torch.float32, device=dev)
+        dep = torch.empty((n, 1, render_size, render_size), dtype=torch.float32, device=dev)
+        T = torch.empty((n, 1, render_size, render_size), dtype=torch.float32, device=dev) if want_transmittance else None
+        status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        if render_size != r.render_h or render_size != r.render_w:
+            r.set_cam(r.cam_fov, render_size, render_size)
+        dhw = r._dhw_on_device()
+        for s in range(0, n, self.batch):
+            chunk = idx[s:s + self.batch]
+            gy = torch.tensor([[float(yaws[i])] for i in chunk], dtype=torch.float32)
+            gp = torch.tensor([[float(pitches[i])] for i in chunk], dtype=torch.float32)
+            _, _, c2w, rays, eyes, zdirs = r.sample_cam_poses(len(chunk), 0.0, 0.0, 0.0, 0.0, False,
+                                                              given_yaws=gy, given_pitches=gp)
+            out = dict(color=rgb[s:s + len(chunk)], depth=dep[s:s + len(chunk)])
+            if T is not None:
+                out["T"] = T[s:s + len(chunk)]
+            r.mpi.render_views(mpi_rgbas, dhw, torch.cat(rays), torch.cat(eyes), torch.cat(zdirs),
+                               views_per_mpi=len(chunk), check_last_plane=True, out_pm1=True,
+                               want_transmittance=want_transmittance, status=status, defer_status=True, out=out)
+        r.mpi.raise_on_status(status)  # one host sync for the whole path
+        res = dict(rgb=rgb, depth=dep, T=T)
+        if to_uint8:
+            near, far = depth_range if depth_range is not None else (r.plane_min_d, r.plane_max_d)
+            res["img8"], res["dep8"] = frames_to_uint8(rgb, dep, near, far)
+        return res
+
+    @torch.no_grad()
+    def render_seeds(self, mpi_rgbas: torch.Tensor, render_size: int, views_per_mpi: int = 1, **render_kwargs):
+        """Random-pose renders of a stack of MPIs [B,D,4,Ht,Wt] (prepare_fake_data.py:58-66 /
+        fid_evaluation.py:116 pattern), `batch` MPIs per launch.  Returns the renderer's 4-tuple, concatenated."""
+        outs = []
+        for s in range(0, mpi_rgbas.shape[0], self.batch):
+            outs.append(self.renderer.render(mpi_rgbas[s:s + self.batch], render_size, render_size,
+                                             views_per_mpi=views_per_mpi, **render_kwargs))
+        return tuple(torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0])))

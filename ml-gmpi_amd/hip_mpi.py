@@ -1,0 +1,248 @@
+"""`MPI` -- the reference's compositor module (gmpi/core/mpi.py:156-436) on the fused HIP kernel.
+
+`MPI.forward` keeps the reference's keyword-only signature, tensor layouts, return values and
+assertion behaviour; the arithmetic runs in ONE kernel launch through the C ABI
+(include/gmpi_render.h -> `gmpi_mpi_render_launch`).  None of the reference's per-call temporaries
+exist: no expand+cat of the volume per view (mpi.py:331-346, replaced by a view->MPI index), no
+D-fold replicated ray tensor (mpi.py:362-366), no separate last-plane homography (mpi.py:381-395,
+folded into a status bit), no min/max passes (mpi.py:185-187).
+
+There is no CPU/PyTorch fallback: tensors must live on a ROCm device and the HIP library must be
+built, otherwise this raises.
+"""
+import ctypes
+import sys
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
+
+
+def _cat(parts: Union[torch.Tensor, Sequence[torch.Tensor]]) -> torch.Tensor:
+    if isinstance(parts, torch.Tensor):
+        return parts
+    return parts[0] if len(parts) == 1 else torch.cat(list(parts), dim=0)
+
+
+class MPI(nn.Module):
+    """Drop-in for `gmpi.core.mpi.MPI`.
+
+    Extra constructor knobs (all optional; defaults reproduce the reference's behaviour):
+      variant        "auto" | "gather" | "lds"  -- kernel selection (GMPI_VARIANT_*)
+      strict_order   one rounding per reference op also in the blend (bit-identical to the oracle)
+      range_check    "touched" (default: alpha/rgba range asserted on the texels the render samples, free),
+                     "full" (extra exhaustive pass = the reference's min/max over the whole volume), "off"
+      on_out_of_plane "exit" (reference: diagnostics + sys.exit(1), mpi.py:110-128) | "raise" (RuntimeError)
+    """
+
+    def __init__(self, align_corners=True, variant: str = "auto", strict_order: bool = False,
+                 range_check: str = "touched", on_out_of_plane: str = "exit"):
+        super().__init__()
+        self._align_corners = align_corners
+        assert variant in _lib.VARIANTS, variant
+        assert range_check in ("touched", "full", "off"), range_check
+        assert on_out_of_plane in ("exit", "raise"), on_out_of_plane
+        self.variant = variant
+        self.strict_order = strict_order
+        self.range_check = range_check
+        self.on_out_of_plane = on_out_of_plane
+
+    # -- host-side shape checks (mpi.py:161-216); the alpha range part happens on the device -----------
+    def check_shapes(self, *, batch_rgba, batch_dhw, batch_ray_dir, batch_eye_pos, batch_z_dir, separate_background):
+        assert (batch_rgba.ndim == 5) and (batch_rgba.shape[2] == 4), (
+            f"Expected rgba to be of shape (#mpi, #planes, 4, texture_height, texture_width), "
+            f"but instead got {batch_rgba.shape}")
+        assert ((batch_dhw.ndim == 3) and (batch_dhw.shape[0] == batch_rgba.shape[0])
+                and (batch_dhw.shape[1] == batch_rgba.shape[1]) and (batch_dhw.shape[2] == 3)), (
+            f"Expected dhw to be of shape (#mpi, #planes, 3), but instead got {batch_dhw.shape} (rgba: {batch_rgba.shape})")
+        n_mpi = batch_rgba.shape[0]
+        assert len(batch_ray_dir) == n_mpi, f"{len(batch_ray_dir)}, {n_mpi}"
+        assert len(batch_eye_pos) == n_mpi, f"{len(batch_eye_pos)}, {n_mpi}"
+        assert len(batch_z_dir) == n_mpi, f"{len(batch_z_dir)}, {n_mpi}"
+        for i in range(n_mpi):
+            assert (batch_ray_dir[i].ndim == 4) and (batch_ray_dir[i].shape[1] == 3), (
+                f"Expected ray_dir to be of shape (minibatch, 3, image_height, image_width), "
+                f"but instead got {batch_ray_dir[i].shape} for {i} th elem.")
+            assert (batch_eye_pos[i].ndim == 2) and (batch_eye_pos[i].shape[1] == 3), (
+                f"Expected eye_pos to be of shape (minibatch, 3), but instead got {batch_eye_pos[i].shape} for {i} th elem.")
+            assert (batch_z_dir[i].ndim == 2) and (batch_z_dir[i].shape[1] == 3), (
+                f"Expected z_dir to be of shape (minibatch, 3), but instead got {batch_z_dir[i].shape} for {i} th elem.")
+        if separate_background is not None:
+            assert separate_background.ndim == 4 and separate_background.shape[1] == 3, (
+                f"Expect background to be of shape (#mpi, 3, h, w), but instead get {separate_background.shape}.")
+
+    # -- the reference entry point -------------------------------------------------------------------------
+    def forward(self, *, batch_rgba: torch.Tensor, batch_dhw: torch.Tensor, batch_ray_dir: List[torch.Tensor],
+                batch_eye_pos: List[torch.Tensor], batch_z_dir: List[torch.Tensor],
+                separate_background: Union[None, torch.Tensor], assert_not_out_of_last_plane: bool = False,
+                c2w_mat: torch.Tensor = None, sphere_c: np.ndarray = None):
+        """(color [N,3,H,W] in [0,1], depth [N,1,H,W]); N = total #views over the per-MPI lists (mpi.py:308-436).
+
+        `separate_background` is shape-checked and otherwise ignored, exactly as in the reference's `forward`.
+        """
+        self.check_shapes(batch_rgba=batch_rgba, batch_dhw=batch_dhw, batch_ray_dir=batch_ray_dir,
+                          batch_eye_pos=batch_eye_pos, batch_z_dir=batch_z_dir, separate_background=separate_background)
+        counts = [int(r.shape[0]) for r in batch_ray_dir]
+        out = self.render_views(batch_rgba, batch_dhw, _cat(batch_ray_dir), _cat(batch_eye_pos), _cat(batch_z_dir),
+                                views_per_mpi=counts, check_last_plane=assert_not_out_of_last_plane,
+                                c2w_mat=c2w_mat, sphere_c=sphere_c)
+        return out["color"], out["depth"]
+
+    # -- flat-tensor entry point used by the renderer / batch driver ------------------------------------------
+    def render_views(self, rgba: torch.Tensor, dhw: torch.Tensor, ray_dir: torch.Tensor, eye_pos: torch.Tensor,
+                     z_dir: torch.Tensor, views_per_mpi: Union[int, Sequence[int]] = 1,
+                     view_to_mpi: Optional[torch.Tensor] = None, check_last_plane: bool = False,
+                     out_pm1: bool = False, want_transmittance: bool = False, c2w_mat=None, sphere_c=None,
+                     status: Optional[torch.Tensor] = None, defer_status: bool = False, out: Optional[dict] = None):
+        """Renders N views in one launch.
+
+        rgba [M,D,4,Ht,Wt] (f32/bf16/f16, any outer strides, innermost contiguous), dhw [M,D,3],
+        ray_dir [N,3,H,W], eye_pos [N,3], z_dir [N,3].  View n samples MPI `view_to_mpi[n]`; without it,
+        `views_per_mpi` (an int or one count per MPI) gives the reference's grouping.
+        Returns dict(color, depth[, T], status).  With `defer_status` the status word is not read back
+        (no host sync); call `raise_on_status` later.
+        """
+        if torch.is_grad_enabled() and (rgba.requires_grad or dhw.requires_grad):
+            raise NotImplementedError("the HIP renderer is forward-only; call it under torch.no_grad() "
+                                      "(backward of the fused op is not implemented)")
+        if not rgba.is_cuda:
+            raise _lib.GmpiError("MPI.forward needs tensors on a ROCm device: this package has no CPU path "
+                                 f"(got rgba on {rgba.device})")
+        lib = _lib.load_library()
+        dev = rgba.device
+        if rgba.dtype not in _DTYPES:
+            rgba = rgba.float()
+        if rgba.stride(4) != 1 or any(s < 0 for s in rgba.stride()):
+            rgba = rgba.contiguous()
+        M, D, _, Ht, Wt = rgba.shape
+        ray_dir = ray_dir.to(dev, torch.float32).contiguous()
+        eye_pos = eye_pos.to(dev, torch.float32).contiguous()
+        z_dir = z_dir.to(dev, torch.float32).contiguous()
+        dhw = dhw.to(dev, torch.float32).contiguous()
+        N, _, H, W = ray_dir.shape
+        assert eye_pos.shape == (N, 3) and z_dir.shape == (N, 3), (eye_pos.shape, z_dir.shape, N)
+        assert dhw.shape == (M, D, 3), (dhw.shape, rgba.shape)
+
+        uniform = 0
+        if view_to_mpi is None:
+            if isinstance(views_per_mpi, int):
+                uniform = views_per_mpi
+            elif len(set(views_per_mpi)) == 1 and len(views_per_mpi) == M:
+                uniform = int(views_per_mpi[0])
+            else:
+                assert len(views_per_mpi) == M and sum(views_per_mpi) == N
+                view_to_mpi = torch.repeat_interleave(torch.arange(M, dtype=torch.int32),
+                                                      torch.tensor(list(views_per_mpi))).to(dev)
+            if uniform:
+                assert N == M * uniform, f"{N} views for {M} MPIs x {uniform}"
+        if view_to_mpi is not None:
+            view_to_mpi = view_to_mpi.to(dev, torch.int32).contiguous()
+            assert view_to_mpi.shape == (N,)
+
+        out = out or {}
+        color = out.get("color")
+        if color is None:
+            color = torch.empty((N, 3, H, W), dtype=torch.float32, device=dev)
+        depth = out.get("depth")
+        if depth is None:
+            depth = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
+        T = None
+        if want_transmittance:
+            T = out.get("T")
+            if T is None:
+                T = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
+        if status is None:
+            status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+
+        flags = 0
+        if self._align_corners:
+            flags |= _lib.FLAG_ALIGN_CORNERS
+        if out_pm1:
+            flags |= _lib.FLAG_OUT_PM1
+        if check_last_plane:
+            flags |= _lib.FLAG_CHECK_LAST_PLANE
+        if self.range_check != "off":
+            flags |= _lib.FLAG_CHECK_RANGE
+        if self.strict_order:
+            flags |= _lib.FLAG_STRICT_ORDER
+
+        p = _lib.GmpiRenderParams()
+        p.struct_size = ctypes.sizeof(_lib.GmpiRenderParams)
+        p.flags = flags
+        p.variant = _lib.VARIANTS[self.variant]
+        p.rgba_dtype = _DTYPES[rgba.dtype]
+        p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W = N, M, D, Ht, Wt, H, W
+        p.views_per_mpi = max(uniform, 1)
+        p.rgba = rgba.data_ptr()
+        for i, s in enumerate(rgba.stride()):
+            p.rgba_stride[i] = s
+        p.view_to_mpi = view_to_mpi.data_ptr() if view_to_mpi is not None else None
+        p.dhw, p.ray_dir, p.eye_pos, p.z_dir = dhw.data_ptr(), ray_dir.data_ptr(), eye_pos.data_ptr(), z_dir.data_ptr()
+        p.rgb_out, p.depth_out = color.data_ptr(), depth.data_ptr()
+        p.transmittance_out = T.data_ptr() if T is not None else None
+        p.status = status.data_ptr()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            if self.range_check == "full":
+                vol = rgba if rgba.is_contiguous() else rgba.contiguous()
+                _lib.check(lib.gmpi_rgba_range_check_launch(vol.data_ptr(), p.rgba_dtype, vol.numel(),
+                                                            status.data_ptr(), stream), "gmpi_rgba_range_check_launch")
+            _lib.check(lib.gmpi_mpi_render_launch(ctypes.byref(p), stream), "gmpi_mpi_render_launch")
+        res = dict(color=color, depth=depth, T=T, status=status)
+        if not defer_status:
+            self.raise_on_status(status, params=p, keep=(rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi),
+                                 c2w_mat=c2w_mat, sphere_c=sphere_c)
+        return res
+
+    # -- status word -> the reference's assertion behaviour ------------------------------------------------------
+    def raise_on_status(self, status: torch.Tensor, params=None, keep=None, c2w_mat=None, sphere_c=None):
+        word = int(status[0].item())  # the only host sync of a render call
+        if word == 0:
+            return
+        if word & _lib.STATUS_RGBA_RANGE:
+            raise AssertionError("Expected alpha to be within the the range [0, 1]")  # mpi.py:185-187
+        if word & _lib.STATUS_CAMERA_BEHIND_PLANE:
+            dist = keep[1][..., 0].flatten().tolist() if keep is not None else "?"
+            eye0 = keep[3][0].tolist() if keep is not None else "?"
+            raise AssertionError(f"Camera must be placed closer to origin than MPI. {dist}, {eye0}")  # mpi.py:70-72
+        if word & _lib.STATUS_OUT_OF_LAST_PLANE:
+            msg = "Ray goes out of the last plane"
+            if params is not None:
+                lib = _lib.load_library()
+                dev = status.device
+                uv = torch.empty((params.N, 4), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.gmpi_last_plane_uv_minmax_launch(ctypes.byref(params), uv.data_ptr(),
+                                                                    torch.cuda.current_stream(dev).cuda_stream),
+                               "gmpi_last_plane_uv_minmax_launch")
+                uv = uv.cpu()
+                mn_u, mx_u, mn_v, mx_v = (float(uv[:, 0].min()), float(uv[:, 1].max()), float(uv[:, 2].min()),
+                                          float(uv[:, 3].max()))
+                dist = keep[1][0, -1, 0].item()
+                if not mn_u >= -1:
+                    msg = f"Ray's U direction goes out of plane at {dist}, min val {mn_u}"
+                elif not mx_u <= 1:
+                    msg = f"Ray's U direction goes out of plane at {dist}, max val {mx_u}"
+                elif not mn_v >= -1:
+                    msg = f"Ray's V direction goes out of plane at {dist}, min val {mn_v}"
+                else:
+                    msg = f"Ray's V direction goes out of plane at {dist}, max val {mx_v}"
+                print("\npos: ", keep[3][:4, :].cpu())
+                print("\ndir: ", keep[2][:4, :3, 0, 0].cpu())
+                if c2w_mat is not None and sphere_c is not None:
+                    from .poses import yaw_pitch_from_w2c
+                    yaws, pitches = yaw_pitch_from_w2c(torch.inverse(c2w_mat.float().cpu()), torch.FloatTensor(sphere_c))
+                    print("\nyaws: ", yaws.numpy().tolist(), "\n")
+                    print("\npitches: ", pitches.numpy().tolist(), "\n")
+            if self.on_out_of_plane == "exit":  # mpi.py:110-128: print the AssertionError and leave
+                print(f"AssertionError: {msg}", file=sys.stderr)
+                sys.exit(1)
+            raise RuntimeError(msg)
+
+
+HipMPI = MPI

@@ -1,0 +1,36 @@
+"""`install()` -- swap the reference's renderer for the HIP one, so that an unmodified
+`gmpi/eval/vis/render_video.py` (which does `from gmpi.core.mpi_renderer import MPIRenderer`,
+render_video.py:11; likewise prepare_fake_data.py:11, train.py:24, eval/common.py:5) runs on it.
+
+Call it after the reference is importable (on PYTHONPATH) and BEFORE the script imports the names:
+
+    import ml_gmpi_amd; ml_gmpi_amd.install()
+    runpy.run_path("gmpi/eval/vis/render_video.py", run_name="__main__")
+"""
+import importlib
+import sys
+
+_SAVED = {}
+
+
+def install(patch_mpi: bool = True, patch_renderer: bool = True) -> None:
+    from .hip_mpi import MPI
+    from .renderer import MPIRenderer
+
+    core_mpi = importlib.import_module("gmpi.core.mpi")
+    core_renderer = importlib.import_module("gmpi.core.mpi_renderer")
+    if patch_mpi:
+        _SAVED.setdefault(("gmpi.core.mpi", "MPI"), core_mpi.MPI)
+        _SAVED.setdefault(("gmpi.core.mpi_renderer", "MPI"), core_renderer.MPI)
+        core_mpi.MPI = MPI
+        core_renderer.MPI = MPI  # `self.mpi = MPI(...)` in the reference's own MPIRenderer (mpi_renderer.py:47)
+    if patch_renderer:
+        _SAVED.setdefault(("gmpi.core.mpi_renderer", "MPIRenderer"), core_renderer.MPIRenderer)
+        core_renderer.MPIRenderer = MPIRenderer
+
+
+def uninstall() -> None:
+    for (mod, name), obj in list(_SAVED.items()):
+        if mod in sys.modules:
+            setattr(sys.modules[mod], name, obj)
+    _SAVED.clear()

@@ -1,0 +1,152 @@
+"""Camera poses on the viewing sphere -> camera-to-world matrices in the MPI frame.
+
+Host-side mirror of the pose chain `MPIRenderer.sample_cam_poses` relies on
+(reference: gmpi/utils/cam_utils.py:481-568 `sample_camera_positions_sphere`, :571-622
+`create_cam2sphere_sys_matrix`, :687-731 `create_sphere2world_sys_matrix_for_coord`, :734-821
+`gen_sphere_path`; gmpi/utils/torch_utils.py:51-76 `truncated_normal`, :87-91 `normalize_vecs`).
+
+The numbers produced here are part of the parity contract (a 1-ulp change of c2w moves every
+sampling position), so the numerical recipe is kept operation-for-operation: float32 torch ops for
+the sphere position and the look-at frame, float64 numpy for the change of frame, and the same
+torch RNG calls in the same order (so a seeded run draws the same poses as the reference).
+tests/test_host_geometry.py checks bit-equality against fixtures produced by the reference.
+
+Frames.  Sphere frame: origin at the sphere centre, +X backward, +Y right, +Z up; yaw is measured
+from +X in the XY plane, pitch from +X in the XZ plane; (yaw, pitch) = (0, 0) faces the MPI.
+MPI/world frame: +X right, +Y down, +Z forward.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+_CPU = torch.device("cpu")
+
+
+def _unit(v: torch.Tensor) -> torch.Tensor:
+    return v / torch.norm(v, dim=-1, keepdim=True)
+
+
+def truncated_normal(n: int, mean: float, std: float, n_stds: float, device=_CPU) -> torch.Tensor:
+    """[n,1] draws from N(mean, std) restricted to mean +- n_stds*std.
+
+    Four candidates per sample (one `normal_()` call on [n,1,4], which is what fixes the RNG
+    consumption), the first candidate strictly inside the bounds wins, and whatever is chosen is
+    clipped to the closed interval.  With std == 0 every candidate equals `mean`.
+    """
+    assert std >= 0, f"{std}"
+    cand = torch.empty((n, 1, 4), dtype=torch.float32, device=device).normal_()
+    cand.mul_(std).add_(mean)
+    lo = mean - 1 * n_stds * std
+    hi = mean + n_stds * std
+    inside = (cand < hi) & (cand > lo)
+    pick = inside.max(-1, keepdim=True)[1]
+    out = cand.gather(-1, pick).squeeze(-1)
+    out[out <= lo] = lo
+    out[out >= hi] = hi
+    return out
+
+
+def sample_sphere_angles(n: int, yaw_mean, yaw_std, pitch_mean, pitch_std, *, random: bool, method: str,
+                         n_stds: float, horizontal_sweep: bool = True, device=_CPU) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(yaws, pitches), each [n,1] float32.  RNG order: yaws first, then pitches."""
+    if random:
+        if method == "uniform":
+            yaws = (torch.rand((n, 1), device=device) - 0.5) * 2 * n_stds * yaw_std + yaw_mean
+            pitches = (torch.rand((n, 1), device=device) - 0.5) * 2 * n_stds * pitch_std + pitch_mean
+        elif method in ("normal", "gaussian"):
+            yaws = torch.randn((n, 1), device=device) * yaw_std + yaw_mean
+            pitches = torch.randn((n, 1), device=device) * pitch_std + pitch_mean
+        elif method == "truncated_gaussian":
+            yaws = truncated_normal(n, yaw_mean, yaw_std, n_stds, device)
+            pitches = truncated_normal(n, pitch_mean, pitch_std, n_stds, device)
+        else:
+            raise ValueError(method)
+    else:
+        sweep = torch.linspace(-n_stds, n_stds, steps=n, device=device).reshape((n, 1))
+        if horizontal_sweep:
+            yaws = sweep * yaw_std + yaw_mean
+            pitches = torch.ones((n, 1), device=device) * pitch_mean
+        else:
+            yaws = torch.ones((n, 1), device=device) * yaw_mean
+            pitches = sweep * pitch_std + pitch_mean
+    return yaws, pitches
+
+
+def sphere_positions(yaws: torch.Tensor, pitches: torch.Tensor, r: float) -> torch.Tensor:
+    """[n,3] camera positions in the sphere frame (float32)."""
+    n = yaws.shape[0]
+    pos = torch.zeros((n, 3), device=yaws.device)
+    ring = r * torch.abs(torch.cos(pitches))
+    pos[:, 0:1] = ring * torch.cos(yaws)
+    pos[:, 1:2] = ring * torch.sin(yaws)
+    pos[:, 2:3] = r * torch.sin(pitches)
+    return pos
+
+
+def look_at_centre(pos: torch.Tensor) -> torch.Tensor:
+    """[n,4,4] float32 camera-to-sphere matrices of cameras at `pos` looking at the origin.
+
+    Camera axes: +X right, +Y down, +Z forward; columns of the rotation are (right, down, forward).
+    """
+    n = pos.shape[0]
+    dev = pos.device
+    fwd = _unit(_unit(-pos))  # the reference normalises twice (gen_sphere_path, then create_cam2sphere_sys_matrix)
+    down0 = torch.tensor([0, 0, -1], dtype=torch.float, device=dev).expand_as(fwd)
+    right = _unit(torch.cross(down0, fwd, dim=-1))
+    down = _unit(torch.cross(fwd, right, dim=-1))
+    rot = torch.eye(4, device=dev).unsqueeze(0).repeat(n, 1, 1)
+    rot[:, :3, :3] = torch.stack((right, down, fwd), axis=-1)
+    trans = torch.eye(4, device=dev).unsqueeze(0).repeat(n, 1, 1)
+    trans[:, :3, 3] = pos
+    return trans @ rot
+
+
+def sphere_to_mpi_frame(sphere_center: np.ndarray) -> np.ndarray:
+    """4x4 float64: sphere-frame coordinates -> MPI-frame coordinates (rotate axes, then move to the centre)."""
+    turn_z = np.eye(4)
+    turn_z[:3, :3] = Rotation.from_euler("Z", -90, degrees=True).as_matrix()  # -> +X right, +Y forward, +Z up
+    turn_x = np.eye(4)
+    turn_x[:3, :3] = Rotation.from_euler("X", 90, degrees=True).as_matrix()   # -> +X right, +Y down, +Z forward
+    rot = np.matmul(turn_x, turn_z)
+    shift = np.eye(4)
+    shift[:3, 3] = np.asarray(sphere_center).reshape(-1)
+    return np.matmul(shift, rot)
+
+
+def gen_sphere_path(n_cams: int, sphere_center: np.ndarray, sphere_r: Optional[float], yaw_mean=0.0,
+                    yaw_std=np.sqrt(np.pi), pitch_mean=0.0, pitch_std=np.sqrt(np.pi), given_yaws=None,
+                    given_pitches=None, flag_rnd=True, flag_det_horizontal=True, sample_method="uniform",
+                    n_truncated_stds=2, device=_CPU):
+    """Same call signature and return value as the reference's `gen_sphere_path` (cam_utils.py:734):
+    (c2w [n,4,4] float64 numpy in the MPI frame, yaws [n,1], pitches [n,1])."""
+    if sphere_r is None:
+        sphere_r = np.linalg.norm(sphere_center, ord=2)
+    if given_yaws is None:
+        assert given_pitches is None
+        yaws, pitches = sample_sphere_angles(n_cams, yaw_mean, yaw_std, pitch_mean, pitch_std, random=flag_rnd,
+                                             method=sample_method, n_stds=n_truncated_stds,
+                                             horizontal_sweep=flag_det_horizontal, device=device)
+    else:
+        yaws, pitches = given_yaws, given_pitches
+    pos = sphere_positions(yaws, pitches, sphere_r)
+    cam2sphere = look_at_centre(pos).cpu().numpy()
+    c2w = np.matmul(sphere_to_mpi_frame(sphere_center), cam2sphere)
+    return c2w, yaws, pitches
+
+
+def yaw_pitch_from_w2c(w2c_mat: torch.Tensor, sphere_c: torch.Tensor):
+    """(yaws, pitches) [B,1] of cameras given world-to-camera matrices [B,4,4] (diagnostics only;
+    mirrors gmpi/utils/cam_utils.py:1005-1050 `compute_pitch_yaw_from_w2c_mat`)."""
+    assert sphere_c.ndim <= 2, f"{sphere_c.shape}"
+    assert w2c_mat.ndim == 3, f"{w2c_mat.shape}"
+    bs = w2c_mat.shape[0]
+    world2sphere = torch.inverse(torch.FloatTensor(sphere_to_mpi_frame(sphere_c.numpy()))).unsqueeze(0).expand(bs, -1, -1)
+    origin = torch.FloatTensor([0, 0, 0, 1]).reshape((1, 4, 1)).expand(bs, -1, -1)
+    cam_in_world = torch.matmul(torch.inverse(w2c_mat), origin)
+    cam_in_sphere = torch.matmul(world2sphere, cam_in_world)[:, :3]
+    cam_in_sphere = cam_in_sphere / torch.norm(cam_in_sphere, p=2, dim=1, keepdim=True)
+    yaws = torch.atan2(cam_in_sphere[:, 1], cam_in_sphere[:, 0])
+    pitches = np.pi / 2 - torch.acos(cam_in_sphere[:, 2])
+    return yaws, pitches

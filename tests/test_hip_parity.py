@@ -1,0 +1,280 @@
+"""GPU parity tests: the HIP renderer (through the C ABI) vs the CPU oracle and vs the golden
+fixtures the reference produced.  Run on the MI355X box:  python -m pytest tests -m gpu
+
+Bars (north star: fp32-equivalent to the reference within 1e-5):
+  * strict-order mode  == oracle, BIT-EXACT (same op sequence, IEEE division, no FMA contraction)
+  * default mode       vs oracle / golden  <= 1e-5 colour ([-1,1] scale), 1e-5 depth (observed ~1e-6)
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _util import load_npz, load_render_fixture, render_fixture_names
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _lib():
+    from ml_gmpi_amd import _lib as L
+    return L
+
+
+def variants():
+    L = _lib()
+    lib = L.load_library()
+    return ["gather", "lds"] if lib.gmpi_query(3) > 0 else ["gather"]
+
+
+def hip_render(rgba, dhw, ray_dir, eye, zdir, *, ac=True, variant="gather", strict=False, view_to_mpi=None,
+               views_per_mpi=1, check_last=True, range_check="touched", dtype=None, out_pm1=False):
+    from ml_gmpi_amd import MPI
+    dev = torch.device("cuda:0")
+    t = lambda a: a.to(dev) if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rgba_t = t(rgba)
+    if dtype is not None:
+        rgba_t = rgba_t.to(dtype)
+    mpi = MPI(align_corners=ac, variant=variant, strict_order=strict, range_check=range_check, on_out_of_plane="raise")
+    v2m = None if view_to_mpi is None else t(np.asarray(view_to_mpi, dtype=np.int32))
+    with torch.no_grad():
+        out = mpi.render_views(rgba_t, t(dhw), t(ray_dir), t(eye), t(zdir), views_per_mpi=views_per_mpi,
+                               view_to_mpi=v2m, check_last_plane=check_last, want_transmittance=True, out_pm1=out_pm1)
+    torch.cuda.synchronize()
+    return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", render_fixture_names())
+def test_golden_fixtures(name):
+    fx = load_render_fixture(name)
+    ac = fx["meta"]["ac"]
+    orc = oracle.render(fx["rgba"], fx["dhw"], fx["ray_dir"], fx["eye"], fx["zdir"], align_corners=ac)
+    for variant in variants():
+        strict = hip_render(fx["rgba"], fx["dhw"], fx["ray_dir"], fx["eye"], fx["zdir"], ac=ac, variant=variant, strict=True)
+        for k in ("color", "depth", "T"):
+            assert np.array_equal(strict[k], orc[k]), (variant, k, np.abs(strict[k] - orc[k]).max())
+        fast = hip_render(fx["rgba"], fx["dhw"], fx["ray_dir"], fx["eye"], fx["zdir"], ac=ac, variant=variant,
+                          out_pm1=True)
+        assert np.abs(fast["color"] - fx["ref_rgb_pm1"]).max() <= TOL, variant
+        assert np.abs(fast["depth"] - fx["ref_depth"]).max() <= TOL, variant
+        assert np.abs(fast["T"] - orc["T"]).max() <= TOL, variant
+        assert int(fast["status"][0]) == 0
+
+
+def test_golden_ragged_views_per_mpi():
+    fx = load_npz("forward_ragged_views.npz")
+    m = fx["meta"]
+    rgba = oracle.synth_rgba(m["seed"], (m["M"], m["D"], 4, *m["tex"]))
+    for variant in variants():
+        out = hip_render(rgba, fx["dhw"], fx["ray_dir"], fx["eye"], fx["zdir"], variant=variant,
+                         views_per_mpi=m["views_per_mpi"])
+        assert np.abs(out["color"] - fx["ref_color01"]).max() <= TOL
+        assert np.abs(out["depth"] - fx["ref_depth"]).max() <= TOL
+        out2 = hip_render(rgba, fx["dhw"], fx["ray_dir"], fx["eye"], fx["zdir"], variant=variant,
+                          view_to_mpi=fx["view_to_mpi"])
+        assert np.array_equal(out["color"], out2["color"]) and np.array_equal(out["depth"], out2["depth"])
+
+
+def _random_case(seed, B, D, S, T=None, preset="FFHQ", extreme=False):
+    """Seeded inputs: white-noise volume (torch CPU RNG) + poses/rays from the host mirror on CPU."""
+    from ml_gmpi_amd.renderer import MPIRenderer, PRESETS
+    T = T or S
+    kw = dict(PRESETS[preset])
+    kw.update(n_mpi_planes=D, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse",
+              cam_sample_method="truncated_gaussian", mpi_align_corners=True, use_confined_volume=True,
+              device=torch.device("cpu"))
+    r = MPIRenderer(**kw)
+    r.set_cam(r.cam_fov, S, S)
+    g = torch.Generator().manual_seed(seed)
+    rgba = torch.rand((B, D, 4, T, T), generator=g)
+    torch.manual_seed(seed)
+    if extreme:
+        n = r.cam_pose_n_truncated_stds
+        gy = torch.tensor([[(-1) ** i * n * r.horizontal_std] for i in range(B)], dtype=torch.float32)
+        gp = torch.tensor([[(-1) ** (i // 2) * n * r.vertical_std] for i in range(B)], dtype=torch.float32)
+        cam = r.sample_cam_poses(B, 0, 0, 0, 0, False, given_yaws=gy, given_pitches=gp)
+    else:
+        cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    dhw = r.static_mpi_plane_dhws.reshape(1, -1, 3).expand(B, -1, -1).contiguous()
+    return rgba, dhw, torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(seed=1, B=2, D=32, S=256),                        # BASELINE config 1 shape, 2 views
+    dict(seed=2, B=2, D=24, S=224, T=256, extreme=True),   # tex != img (prepare_fake_data.py:105-108), rays leave planes
+    dict(seed=3, B=1, D=96, S=512),                        # config 4 shape, one view
+    dict(seed=4, B=3, D=7, S=100, T=77),                   # odd sizes (not multiples of the tile / of 4 texels)
+    dict(seed=5, B=1, D=12, S=128, preset="AFHQCat"),
+])
+def test_oracle_parity_random_white_noise(cfg):
+    rgba, dhw, ray, eye, zd = _random_case(**cfg)
+    orc = oracle.render(rgba, dhw, ray, eye, zd, threads=True)
+    for variant in variants():
+        strict = hip_render(rgba, dhw, ray, eye, zd, variant=variant, strict=True)
+        for k in ("color", "depth", "T"):
+            assert np.array_equal(strict[k], orc[k]), (variant, k, np.abs(strict[k] - orc[k]).max())
+        fast = hip_render(rgba, dhw, ray, eye, zd, variant=variant)
+        assert np.abs(fast["color"] - orc["color"]).max() <= 0.5 * TOL  # [0,1] scale = half the [-1,1] bar
+        assert np.abs(fast["depth"] - orc["depth"]).max() <= TOL
+        assert np.abs(fast["T"] - orc["T"]).max() <= TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_half_storage_is_exact_upcast(dtype):
+    rgba, dhw, ray, eye, zd = _random_case(seed=7, B=2, D=16, S=128)
+    stored = rgba.to(dtype)
+    orc = oracle.render(stored.float(), dhw, ray, eye, zd)  # reference upcasts: mpi_renderer.py:446
+    for variant in variants():
+        out = hip_render(stored, dhw, ray, eye, zd, variant=variant, strict=True)
+        assert np.array_equal(out["color"], orc["color"]) and np.array_equal(out["depth"], orc["depth"]), variant
+
+
+def test_expanded_volume_strides():
+    """`expand`ed batch (stride 0 on the MPI axis, prepare_fake_data.py:62-63) and a sliced (padded-row) volume."""
+    rgba, dhw, ray, eye, zd = _random_case(seed=8, B=3, D=6, S=64)
+    one = rgba[:1]
+    orc = oracle.render(one.expand(3, -1, -1, -1, -1).contiguous(), dhw, ray, eye, zd)
+    dev = torch.device("cuda:0")
+    exp = one.to(dev).expand(3, -1, -1, -1, -1)
+    assert exp.stride(0) == 0
+    for variant in variants():
+        out = hip_render(exp, dhw, ray, eye, zd, variant=variant, strict=True)
+        assert np.array_equal(out["color"], orc["color"]), variant
+        out = hip_render(one, dhw, ray, eye, zd, variant=variant, strict=True, views_per_mpi=3)
+        assert np.array_equal(out["color"], orc["color"]), variant
+    big = torch.rand((3, 6, 4, 70, 80), generator=torch.Generator().manual_seed(9)).to(dev)
+    view = big[:, :, :, 3:67, 8:72]  # row stride 80, 64x64 window
+    assert not view.is_contiguous() and view.stride(4) == 1
+    orc = oracle.render(view.cpu().contiguous(), dhw, ray, eye, zd)
+    for variant in variants():
+        out = hip_render(view, dhw, ray, eye, zd, variant=variant, strict=True)
+        assert np.array_equal(out["color"], orc["color"]), variant
+
+
+def test_status_bits_and_reference_assertions():
+    from ml_gmpi_amd import MPI
+    rgba, dhw, ray, eye, zd = _random_case(seed=10, B=2, D=5, S=48)
+    dev = torch.device("cuda:0")
+    bad = rgba.clone()
+    bad[1, 2, 3] = 1.25
+    for variant in variants():
+        with pytest.raises(AssertionError, match="alpha to be within"):
+            hip_render(bad, dhw, ray, eye, zd, variant=variant)
+        out = hip_render(bad, dhw, ray, eye, zd, variant=variant, range_check="off")  # no flag, still renders
+        assert int(out["status"][0]) == 0
+        nan = rgba.clone()
+        nan[0, 0, 0, 5, 5] = float("nan")
+        with pytest.raises(AssertionError):
+            hip_render(nan, dhw, ray, eye, zd, variant=variant, range_check="full")
+        small = dhw.clone()
+        small[:, -1, 1:] *= 0.25
+        with pytest.raises(RuntimeError, match="goes out of plane"):
+            hip_render(rgba, small, ray, eye, zd, variant=variant)
+        hip_render(rgba, small, ray, eye, zd, variant=variant, check_last=False)  # assert disabled -> fine
+        behind = dhw.clone()
+        behind[:, 0, 0] = -5.0
+        with pytest.raises(AssertionError, match="Camera must be placed closer"):
+            hip_render(rgba, behind, ray, eye, zd, variant=variant)
+    # reference behaviour: print + sys.exit(1)   (mpi.py:110-128)
+    mpi = MPI(on_out_of_plane="exit")
+    with pytest.raises(SystemExit):
+        with torch.no_grad():
+            mpi.forward(batch_rgba=rgba.to(dev), batch_dhw=small.to(dev), batch_ray_dir=[r[None].to(dev) for r in ray],
+                        batch_eye_pos=[e[None].to(dev) for e in eye], batch_z_dir=[z[None].to(dev) for z in zd],
+                        separate_background=None, assert_not_out_of_last_plane=True)
+
+
+def test_last_plane_uv_diagnostics_match_oracle():
+    import ctypes
+    L = _lib()
+    lib = L.load_library()
+    rgba, dhw, ray, eye, zd = _random_case(seed=11, B=3, D=5, S=40)
+    orc = oracle.render(rgba, dhw, ray, eye, zd)
+    dev = torch.device("cuda:0")
+    d_dhw, d_ray, d_eye = dhw.to(dev), ray.to(dev), eye.to(dev)
+    p = L.GmpiRenderParams()
+    p.struct_size = ctypes.sizeof(L.GmpiRenderParams)
+    p.flags = L.FLAG_ALIGN_CORNERS
+    p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W, p.views_per_mpi = 3, 3, 5, 40, 40, 40, 40, 1
+    p.dhw, p.ray_dir, p.eye_pos = d_dhw.data_ptr(), d_ray.data_ptr(), d_eye.data_ptr()
+    uv = torch.empty((3, 4), device=dev)
+    assert lib.gmpi_last_plane_uv_minmax_launch(ctypes.byref(p), uv.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(uv.cpu().numpy(), orc["uv_minmax"])
+
+
+def test_c_abi_rejects_bad_arguments():
+    import ctypes
+    L = _lib()
+    lib = L.load_library()
+    assert lib.gmpi_mpi_render_launch(None, None) == -1
+    p = L.GmpiRenderParams()
+    assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == -5  # struct_size 0
+    p.struct_size = ctypes.sizeof(L.GmpiRenderParams)
+    assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == -2  # zero extents
+    p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W, p.views_per_mpi = 1, 1, 1, 4, 4, 4, 4, 1
+    assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == -1  # null pointers
+
+
+def test_mpi_forward_signature_and_renderer_render():
+    """The reference-facing classes: MPI.forward(list-of-tensors kwargs) and MPIRenderer.render(given_cam_infos)."""
+    from ml_gmpi_amd import MPI, make_renderer
+    fx = load_render_fixture("ffhq_d8_32_ac1")
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    B = fx["meta"]["B"]
+    mpi = MPI(align_corners=True)
+    with torch.no_grad():
+        color, depth = mpi(batch_rgba=t(fx["rgba"]), batch_dhw=t(fx["dhw"]),
+                           batch_ray_dir=[t(fx["ray_dir"][i:i + 1]) for i in range(B)],
+                           batch_eye_pos=[t(fx["eye"][i:i + 1]) for i in range(B)],
+                           batch_z_dir=[t(fx["zdir"][i:i + 1]) for i in range(B)],
+                           separate_background=None, assert_not_out_of_last_plane=True)
+    assert color.shape == (B, 3, 32, 32) and depth.shape == (B, 1, 32, 32)
+    assert np.abs((2 * color - 1).cpu().numpy() - fx["ref_rgb_pm1"]).max() <= TOL
+    r = make_renderer("FFHQ", n_planes=8, device=dev)
+    assert np.array_equal(r.static_mpi_plane_dhws.numpy(), fx["dhw"][0])
+    infos = dict(batch_yaws=torch.from_numpy(fx["yaws"]), batch_pitches=torch.from_numpy(fx["pitches"]),
+                 batch_tf_c2w=t(fx["c2w"]), batch_ray_dir=[t(fx["ray_dir"][i:i + 1]) for i in range(B)],
+                 batch_eye_pos=[t(fx["eye"][i:i + 1]) for i in range(B)],
+                 batch_z_dir=[t(fx["zdir"][i:i + 1]) for i in range(B)])
+    with torch.no_grad():
+        rgb, dep, c2w, ang = r.render(t(fx["rgba"]), 32, 32, given_cam_infos=infos)
+    assert np.abs(rgb.cpu().numpy() - fx["ref_rgb_pm1"]).max() <= TOL
+    assert np.abs(dep.cpu().numpy() - fx["ref_depth"]).max() <= TOL
+    assert np.array_equal(ang.cpu().numpy(), fx["ref_angles"])
+    # sampled poses on the device: same RNG stream as the reference -> same angles / c2w; rays come from the
+    # device matmul (ulps away from the CPU BLAS, like the reference on a GPU)
+    torch.manual_seed(fx["meta"]["seed"])
+    with torch.no_grad():
+        rgb2, dep2, c2w2, ang2 = r.render(t(fx["rgba"]), 32, 32)
+    assert np.array_equal(ang2.cpu().numpy(), fx["ref_angles"])
+    assert np.array_equal(c2w2.cpu().numpy(), fx["c2w"])
+    assert np.abs(rgb2.cpu().numpy() - fx["ref_rgb_pm1"]).max() <= 5e-3  # 1-ulp rays on white noise
+    with pytest.raises(NotImplementedError):
+        x = t(fx["rgba"]).requires_grad_(True)
+        r.render(x, 32, 32, given_cam_infos=infos)
+    with pytest.raises(Exception):
+        r.mpi.render_views(torch.from_numpy(fx["rgba"]), torch.from_numpy(fx["dhw"]), torch.from_numpy(fx["ray_dir"]),
+                           torch.from_numpy(fx["eye"]), torch.from_numpy(fx["zdir"]))  # CPU tensors: no fallback
+
+
+def test_frames_to_uint8_matches_numpy_recipe():
+    from ml_gmpi_amd import frames_to_uint8
+    g = torch.Generator().manual_seed(3)
+    rgb = torch.rand((2, 3, 33, 31), generator=g) * 2 - 1
+    dep = torch.rand((2, 1, 33, 31), generator=g) * 0.3 + 0.9
+    img8, dep8 = frames_to_uint8(rgb.cuda(), dep.cuda(), 0.95, 1.12)
+    img = rgb.permute(0, 2, 3, 1).numpy()
+    img = (img + 1) / 2.0
+    want = (img * 255).astype(np.uint8)  # render_video.py:118-121
+    d = dep.permute(0, 2, 3, 1).numpy()
+    d = (d - 0.95) / (1.12 - 0.95)
+    d = np.clip(d, 0, 1)
+    want_d = (d * 255).astype(np.uint8)  # render_video.py:123-126
+    assert np.array_equal(img8.cpu().numpy(), want)
+    assert np.array_equal(dep8.cpu().numpy(), want_d)

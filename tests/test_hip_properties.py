@@ -1,0 +1,116 @@
+"""Size-independent properties of the render path at BASELINE.json's full sizes (the CPU oracle
+needs ~10 GB and minutes per 1024^2 x 96 view, so full-size parity is checked through invariants):
+
+  * constant-colour volume:       C = c * (1 - T_final)                 (sum of weights = 1 - prod(1-a))
+  * opaque far plane:             T_final == 0 and sum(weights) == 1 -> depth inside [near, far]
+  * batch invariance:             N views in one launch == the same views one by one (bit-exact)
+  * plane-split associativity:    composite(planes[:k]) (+) composite(planes[k:]) == composite(all)
+                                  with (C1,Z1,T1)(+)(C2,Z2,T2) = (C1+T1*C2, Z1+T1*Z2, T1*T2)
+  * identity of variants:         gather and LDS kernels agree bit-exactly in strict-order mode
+  * sub-region parity:            a 64x64 pixel window of the full-size render == the oracle run on
+                                  that window's rays (bit-exact in strict mode)
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def variants():
+    from ml_gmpi_amd import _lib as L
+    return ["gather", "lds"] if L.load_library().gmpi_query(3) > 0 else ["gather"]
+
+
+def setup(S, D, B, preset="FFHQ", dtype=torch.float32, seed=0, last_alpha_one=False):
+    from ml_gmpi_amd import make_renderer
+    dev = torch.device(DEV)
+    r = make_renderer(preset, n_planes=D, device=dev, on_out_of_plane="raise")
+    r.set_cam(r.cam_fov, S, S)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    rgba = torch.rand((B, D, 4, S, S), device=dev, generator=g, dtype=torch.float32)
+    if last_alpha_one:
+        rgba[:, -1, 3] = 1.0
+    rgba = rgba.to(dtype)
+    torch.manual_seed(seed)
+    cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    dhw = r._dhw_on_device().expand(B, -1, -1).contiguous()
+    return r, rgba, dhw, torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+
+
+def run(r, rgba, dhw, ray, eye, zd, variant, strict=False, **kw):
+    r.mpi.variant, r.mpi.strict_order = variant, strict
+    with torch.no_grad():
+        return r.mpi.render_views(rgba, dhw, ray, eye, zd, want_transmittance=True, check_last_plane=True, **kw)
+
+
+@pytest.mark.parametrize("shape", [dict(S=1024, D=96, B=2, dtype=torch.bfloat16),   # config 3 shape (bf16 storage)
+                                   dict(S=256, D=96, B=8, dtype=torch.float32),      # config 2
+                                   dict(S=512, D=96, B=2, dtype=torch.float32)])     # config 4 per-GPU slice
+def test_constant_colour_and_opaque_background(shape):
+    r, rgba, dhw, ray, eye, zd = setup(last_alpha_one=True, seed=3, **shape)
+    c = torch.tensor([0.25, 0.5, 0.75], device=rgba.device, dtype=rgba.dtype)
+    rgba[:, :, :3] = c.view(1, 1, 3, 1, 1)
+    for variant in variants():
+        out = run(r, rgba, dhw, ray, eye, zd, variant)
+        T, C, Z = out["T"], out["color"], out["depth"]
+        want = c.float().view(1, 3, 1, 1) * (1.0 - T)
+        assert float((C - want).abs().max()) <= 2e-6, variant
+        assert float(T.abs().max()) <= 1e-9  # opaque last plane, every ray hits it (status checked)
+        assert float(Z.min()) >= r.plane_min_d * 0.999 and float(Z.max()) <= r.plane_max_d * 1.03, variant
+
+
+@pytest.mark.parametrize("shape", [dict(S=1024, D=96, B=2, dtype=torch.bfloat16), dict(S=256, D=96, B=8, dtype=torch.float32)])
+def test_batch_invariance_and_variant_identity(shape):
+    r, rgba, dhw, ray, eye, zd = setup(seed=4, **shape)
+    ref = None
+    for variant in variants():
+        full = run(r, rgba, dhw, ray, eye, zd, variant, strict=True)
+        if ref is None:
+            ref = full
+        else:  # both kernels: same bits in strict mode
+            for k in ("color", "depth", "T"):
+                assert torch.equal(full[k], ref[k]), (variant, k)
+        for i in (0, rgba.shape[0] - 1):
+            one = run(r, rgba[i:i + 1], dhw[i:i + 1], ray[i:i + 1], eye[i:i + 1], zd[i:i + 1], variant, strict=True)
+            for k in ("color", "depth", "T"):
+                assert torch.equal(one[k][0], full[k][i]), (variant, k, i)
+        fast = run(r, rgba, dhw, ray, eye, zd, variant, strict=False)
+        assert float((fast["color"] - full["color"]).abs().max()) <= 5e-6
+        assert float((fast["depth"] - full["depth"]).abs().max()) <= 1e-5
+
+
+def test_plane_split_associativity_full_size():
+    r, rgba, dhw, ray, eye, zd = setup(S=1024, D=96, B=1, dtype=torch.float32, seed=5)
+    k = 40
+    for variant in variants():
+        r.mpi.variant = variant
+        whole = run(r, rgba, dhw, ray, eye, zd, variant)
+        r.mpi.range_check = "touched"
+        front = r.mpi.render_views(rgba[:, :k], dhw[:, :k].contiguous(), ray, eye, zd, want_transmittance=True)
+        back = r.mpi.render_views(rgba[:, k:], dhw[:, k:].contiguous(), ray, eye, zd, want_transmittance=True)
+        C = front["color"] + front["T"] * back["color"]
+        Z = front["depth"] + front["T"] * back["depth"]
+        T = front["T"] * back["T"]
+        assert float((C - whole["color"]).abs().max()) <= 2e-6, variant
+        assert float((Z - whole["depth"]).abs().max()) <= 4e-6, variant
+        assert float((T - whole["T"]).abs().max()) <= 1e-6, variant
+
+
+@pytest.mark.parametrize("shape", [dict(S=1024, D=96, B=1, dtype=torch.bfloat16), dict(S=1024, D=256, B=1, dtype=torch.float32, preset="MetFaces")])
+def test_full_size_window_against_oracle(shape):
+    """Oracle on the rays of a few 64x64 windows of the full-size image (the volume is full size)."""
+    r, rgba, dhw, ray, eye, zd = setup(seed=6, **shape)
+    vol = rgba.float().cpu().numpy()
+    S = shape["S"]
+    for variant in variants():
+        out = run(r, rgba, dhw, ray, eye, zd, variant, strict=True)
+        for (y0, x0) in [(0, 0), (S - 64, S - 64), (S // 2 - 32, S // 2 + 7), (13, S - 64)]:
+            win = ray[:, :, y0:y0 + 64, x0:x0 + 64].contiguous().cpu()
+            orc = oracle.render(vol, dhw.cpu(), win, eye.cpu(), zd.cpu(), threads=True)
+            for key in ("color", "depth", "T"):
+                got = out[key][:, :, y0:y0 + 64, x0:x0 + 64].cpu().numpy()
+                assert np.array_equal(got, orc[key]), (variant, key, y0, x0, np.abs(got - orc[key]).max())
