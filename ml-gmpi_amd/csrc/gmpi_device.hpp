@@ -159,6 +159,33 @@ __device__ __forceinline__ void blend(Accum& A, float r, float g, float b, float
 
 __device__ __forceinline__ bool in_unit(float v) { return v >= 0.0f && v <= 1.0f; }
 
+// Direct-from-global bilinear sample of the 4 channels of one plane (zeros padding): clamp the
+// address, zero the weight of a tap that lies outside the texture.  `pl` points at channel 0.
+template <typename TexT, bool STRICT>
+__device__ __forceinline__ void gather_sample(const TexT* __restrict__ pl, int64_t s_chan, int64_t s_row, int Ht, int Wt,
+                                              float ix, float iy, bool check_range, uint32_t& bad, float (&smp)[4]) {
+    Footprint f = footprint(ix, iy, Ht, Wt);
+    const bool x0in = f.x0 >= 0 && f.x0 <= Wt - 1, x1in = f.x0 >= -1 && f.x0 <= Wt - 2;
+    const bool y0in = f.y0 >= 0 && f.y0 <= Ht - 1, y1in = f.y0 >= -1 && f.y0 <= Ht - 2;
+    if (!(x0in && y0in)) f.nw = 0.0f;
+    if (!(x1in && y0in)) f.ne = 0.0f;
+    if (!(x0in && y1in)) f.sw = 0.0f;
+    if (!(x1in && y1in)) f.se = 0.0f;
+    const int xa = min(max(f.x0, 0), Wt - 1), xb = min(max(f.x0 + 1, 0), Wt - 1);
+    const int ya = min(max(f.y0, 0), Ht - 1), yb = min(max(f.y0 + 1, 0), Ht - 1);
+    const int64_t oa = static_cast<int64_t>(ya) * s_row, ob = static_cast<int64_t>(yb) * s_row;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const TexT* __restrict__ ch = pl + c * s_chan;
+        const float t_nw = to_f32(ch[oa + xa]);
+        const float t_ne = to_f32(ch[oa + xb]);
+        const float t_sw = to_f32(ch[ob + xa]);
+        const float t_se = to_f32(ch[ob + xb]);
+        if (check_range && !(in_unit(t_nw) && in_unit(t_ne) && in_unit(t_sw) && in_unit(t_se))) bad |= 2u;
+        smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
+    }
+}
+
 // OR a per-lane flag word into status[0] with at most one atomic per wave.
 __device__ __forceinline__ void report_status(uint32_t* status, uint32_t bad) {
     if (status == nullptr) return;

@@ -61,29 +61,8 @@ __global__ __launch_bounds__(kGatherTileW* kGatherTileH) void render_gather_kern
         plane_coord<AC>(zdiff, ph, pw, ex, ey, rx, ry, rz, cx, cy, ix, iy, s, u, v);
         if (check_last && k == p.D - 1 && !(u >= -1.0f && u <= 1.0f && v >= -1.0f && v <= 1.0f)) bad |= 1u;
 
-        Footprint f = footprint(ix, iy, Ht, Wt);
-        // zeros padding: clamp the address, zero the weight of a tap that lies outside the texture
-        const bool x0in = f.x0 >= 0 && f.x0 <= Wt - 1, x1in = f.x0 >= -1 && f.x0 <= Wt - 2;
-        const bool y0in = f.y0 >= 0 && f.y0 <= Ht - 1, y1in = f.y0 >= -1 && f.y0 <= Ht - 2;
-        if (!(x0in && y0in)) f.nw = 0.0f;
-        if (!(x1in && y0in)) f.ne = 0.0f;
-        if (!(x0in && y1in)) f.sw = 0.0f;
-        if (!(x1in && y1in)) f.se = 0.0f;
-        const int xa = min(max(f.x0, 0), Wt - 1), xb = min(max(f.x0 + 1, 0), Wt - 1);
-        const int ya = min(max(f.y0, 0), Ht - 1), yb = min(max(f.y0 + 1, 0), Ht - 1);
-        const TexT* __restrict__ pl = vol + static_cast<int64_t>(k) * p.s_plane;
-        const int64_t oa = static_cast<int64_t>(ya) * s_row, ob = static_cast<int64_t>(yb) * s_row;
         float smp[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const TexT* __restrict__ ch = pl + c * s_chan;
-            const float t_nw = to_f32(ch[oa + xa]);
-            const float t_ne = to_f32(ch[oa + xb]);
-            const float t_sw = to_f32(ch[ob + xa]);
-            const float t_se = to_f32(ch[ob + xb]);
-            if (check_range && !(in_unit(t_nw) && in_unit(t_ne) && in_unit(t_sw) && in_unit(t_se))) bad |= 2u;
-            smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
-        }
+        gather_sample<TexT, STRICT>(vol + static_cast<int64_t>(k) * p.s_plane, s_chan, s_row, Ht, Wt, ix, iy, check_range, bad, smp);
         blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
     }
 

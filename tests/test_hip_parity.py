@@ -40,9 +40,20 @@ def hip_render(rgba, dhw, ray_dir, eye, zdir, *, ac=True, variant="gather", stri
         rgba_t = rgba_t.to(dtype)
     mpi = MPI(align_corners=ac, variant=variant, strict_order=strict, range_check=range_check, on_out_of_plane="raise")
     v2m = None if view_to_mpi is None else t(np.asarray(view_to_mpi, dtype=np.int32))
+    from ml_gmpi_amd import GmpiError
+    args = (rgba_t, t(dhw), t(ray_dir), t(eye), t(zdir))
+    kw = dict(views_per_mpi=views_per_mpi, view_to_mpi=v2m, check_last_plane=check_last, want_transmittance=True,
+              out_pm1=out_pm1)
     with torch.no_grad():
-        out = mpi.render_views(rgba_t, t(dhw), t(ray_dir), t(eye), t(zdir), views_per_mpi=views_per_mpi,
-                               view_to_mpi=v2m, check_last_plane=check_last, want_transmittance=True, out_pm1=out_pm1)
+        try:
+            out = mpi.render_views(*args, **kw)
+        except GmpiError as e:
+            # shapes the LDS kernel cannot stage (texture width not a multiple of 4, unaligned strides) must be
+            # refused when forced and handled by "auto" (which then picks the gather kernel)
+            if variant != "lds" or "GMPI_E_VARIANT" not in str(e):
+                raise
+            mpi.variant = "auto"
+            out = mpi.render_views(*args, **kw)
     torch.cuda.synchronize()
     return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in out.items()}
 
@@ -144,7 +155,7 @@ def test_expanded_volume_strides():
     for variant in variants():
         out = hip_render(exp, dhw, ray, eye, zd, variant=variant, strict=True)
         assert np.array_equal(out["color"], orc["color"]), variant
-        out = hip_render(one, dhw, ray, eye, zd, variant=variant, strict=True, views_per_mpi=3)
+        out = hip_render(one, dhw[:1], ray, eye, zd, variant=variant, strict=True, views_per_mpi=3)
         assert np.array_equal(out["color"], orc["color"]), variant
     big = torch.rand((3, 6, 4, 70, 80), generator=torch.Generator().manual_seed(9)).to(dev)
     view = big[:, :, :, 3:67, 8:72]  # row stride 80, 64x64 window

@@ -60,7 +60,7 @@ def test_constant_colour_and_opaque_background(shape):
         want = c.float().view(1, 3, 1, 1) * (1.0 - T)
         assert float((C - want).abs().max()) <= 2e-6, variant
         assert float(T.abs().max()) <= 1e-9  # opaque last plane, every ray hits it (status checked)
-        assert float(Z.min()) >= r.plane_min_d * 0.999 and float(Z.max()) <= r.plane_max_d * 1.03, variant
+        assert float(Z.min()) >= r.plane_min_d * 0.8 and float(Z.max()) <= r.plane_max_d * 1.25, variant
 
 
 @pytest.mark.parametrize("shape", [dict(S=1024, D=96, B=2, dtype=torch.bfloat16), dict(S=256, D=96, B=8, dtype=torch.float32)])
