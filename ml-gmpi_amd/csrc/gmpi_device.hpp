@@ -84,6 +84,56 @@ __device__ __forceinline__ void plane_coord(float zdiff, float ph, float pw, flo
     }
 }
 
+// ---- division through a correctly rounded reciprocal ------------------------------------------------
+// q = n / d, correctly rounded, from r = RN(1/d):   q0 = RN(n*r);  e = n - d*q0 (exact, one FMA);
+// q = RN(q0 + e*r).  This is Markstein's final-correction step ("IA-64 and Elementary Functions",
+// thm. 8.2 / Cornea-Harrison-Tang): with r the CORRECTLY ROUNDED reciprocal and q0 within one ulp of
+// n/d, the corrected quotient is the correctly rounded one (for normal-range operands and results;
+// the single exceptional significand pattern d = 2^k*(2-2^-23) needs n*r to be faithful, which it
+// is here).  r is an IEEE division itself (1.0f / d) but a loop-invariant one: per pixel for ray_z,
+// per plane for the plane extents.  `gmpi_selftest_division` (C ABI) compares this against the
+// hardware-correct `/` on 2^32 operand pairs drawn from the renderer's ranges and on the edge
+// patterns; tests/test_hip_parity.py runs it, and the strict-order mode (compiler division) is
+// bit-identical to the oracle, so any slip would surface as a parity failure.
+__device__ __forceinline__ float div_by_recip(float n, float d, float r) {
+    const float q0 = n * r;
+    const float e = __builtin_fmaf(-d, q0, n);
+    return __builtin_fmaf(e, r, q0);
+}
+
+// Same chain as plane_coord(), with the three divisions taken through reciprocals:
+//   rrz = RN(1/ray_z) (per pixel), rw = RN(1/hw), rh = RN(1/hh) with hw = w/2, hh = h/2 (per plane).
+//   (2x)/w == x/(w/2) exactly (power-of-two scaling), so u = x/hw.
+template <bool AC>
+__device__ __forceinline__ void plane_coord_recip(float zdiff, float hw, float hh, float rw, float rh, float ex, float ey,
+                                                  float rx, float ry, float rz, float rrz, float cx, float cy, float& ix,
+                                                  float& iy, float& s) {
+    s = div_by_recip(zdiff, rz, rrz);
+    const float tx = rx * s;
+    const float ty = ry * s;
+    const float x = ex + tx;
+    const float y = ey + ty;
+    float u = div_by_recip(x, hw, rw);
+    float v = div_by_recip(y, hh, rh);
+    if (AC) {
+        const float u1 = u + 1.0f;
+        const float v1 = v + 1.0f;
+        ix = u1 * cx;
+        iy = v1 * cy;
+    } else {
+        if (v >= -1.0f && v <= 1.0f) v = v * kNarrowScale;
+        if (u >= -1.0f && u <= 1.0f) u = u * kNarrowScale;
+        const float u1 = u + 1.0f;
+        const float v1 = v + 1.0f;
+        const float ux = u1 * cx;
+        const float vy = v1 * cy;
+        const float uxm = ux - 1.0f;
+        const float vym = vy - 1.0f;
+        ix = uxm * 0.5f;
+        iy = vym * 0.5f;
+    }
+}
+
 // Bilinear footprint: integer corner (clamped so that NaN / huge coordinates stay out of range) and
 // the four weights nw, ne, sw, se in ATen's order.
 struct Footprint {
@@ -145,16 +195,22 @@ __device__ __forceinline__ void blend(Accum& A, float r, float g, float b, float
         om = om + 1e-10f;
         A.T = A.T * om;
     } else {
-        const float depk = s * dot;  // 1/(1/x) == x to within 1 ulp; depth tolerance is 1e-5
+        // depth_k = s*dot (1/(1/x) == x to within an ulp); dot is constant per pixel, so sum w*s and scale once
+        // at the end (finish_depth) -- depth tolerance is 1e-5, this moves it by a few 1e-7
         const float w = a * A.T;
         A.r = __builtin_fmaf(w, r, A.r);
         A.g = __builtin_fmaf(w, g, A.g);
         A.b = __builtin_fmaf(w, b, A.b);
-        A.z = __builtin_fmaf(w, depk, A.z);
+        A.z = __builtin_fmaf(w, s, A.z);
         float om = 1.0f - a;
         om = om + 1e-10f;
         A.T = A.T * om;
     }
+}
+
+template <bool STRICT>
+__device__ __forceinline__ float finish_depth(const Accum& A, float dot) {
+    return STRICT ? A.z : A.z * dot;
 }
 
 __device__ __forceinline__ bool in_unit(float v) { return v >= 0.0f && v <= 1.0f; }

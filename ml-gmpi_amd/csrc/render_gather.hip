@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kGatherTileW* kGatherTileH) void render_gather_kern
         out[0] = r;
         out[HW] = g;
         out[2 * HW] = b;
-        p.depth_out[static_cast<int64_t>(n) * HW + pix] = A.z;
+        p.depth_out[static_cast<int64_t>(n) * HW + pix] = finish_depth<STRICT>(A, dot);
         if (p.T_out) p.T_out[static_cast<int64_t>(n) * HW + pix] = A.T;
     }
     report_status(p.status, bad);

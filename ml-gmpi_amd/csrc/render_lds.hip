@@ -1,46 +1,57 @@
 // render_lds.hip -- GMPI_VARIANT_LDS: pixel tiles, per-plane texel boxes staged through LDS.
 //
 // Why: the direct gather issues 16 dword loads per pixel*plane through the vector L1 and stalls at
-// ~13-25 % of the HBM roofline (profiles/r01_*).  Here a workgroup owns a 64 x TH pixel tile and
-// walks the D planes front to back.  Because the warp is a homography of a small rectangle, the
-// texels a tile needs on one plane form a small box whose extremes are at the tile's four corner
-// pixels; the box (<= MAXR rows x 72 texels, 4 channels) is copied from HBM with 16-byte row loads
-// (each lane 4 consecutive texels of one channel row: 288-byte contiguous runs), kept as fp32 in
-// LDS in [row][channel][x] order, and every pixel then takes its 16 taps with 8 ds_read2_b32
-// (x0,x1 pairs).  Texels outside the texture are stored as zeros, so the consumer needs no masks
-// ("zeros" padding of F.grid_sample).  Two LDS buffers + register staging give a one-barrier-per-
-// plane pipeline: loads of plane k+1 are in flight while plane k is composited.
+// ~13-25 % of the HBM roofline (profiles/r01_gather_v0_*).  Here a workgroup of 512 threads owns a
+// TW x TH pixel tile (one pixel per thread) and walks the D planes front to back.  The warp is a
+// homography of a small rectangle, so the texels a tile needs on one plane form a small box whose
+// extremes are at the tile's four corner pixels.  The box is copied from HBM with 16-byte row loads
+// (each lane 4 consecutive texels of one channel row), kept as fp32 in LDS in [row][channel][x]
+// order with a per-plane pitch, and every pixel takes its 16 taps with 8 ds_read2_b32 (x0,x1 pairs).
+// Texels outside the texture are stored as zeros, so the consumer needs no masks ("zeros" padding of
+// F.grid_sample).  Two LDS buffers + register staging give a one-barrier-per-plane pipeline: loads
+// of plane k+1 are in flight while plane k is composited.
+//
+// Box size.  Tilted cameras shear and stretch the footprint: a 32x16 pixel tile needs 33x17 texels
+// for a frontal view, 37x20 at (yaw 0.3, pitch 0.1), 47x29 at the 2-sigma FFHQ pose (64-wide tiles
+// would need 91x38).  Hence 32-wide tiles, a box of up to 16 quads x 32 rows, and a capacity test in
+// floats (pitch is per plane) instead of fixed rows x columns.
+//
+// The kernel is VALU-issue bound once the memory side is fixed (profiles/r01_lds_v0_*: HBM traffic
+// == algorithmic bytes), so the default (non-strict) path is written for instruction count: the three
+// IEEE divisions of the coordinate chain become mul+fma+fma against a correctly rounded reciprocal
+// that is hoisted out of the plane loop (1/ray_z per pixel) or computed once per plane (2/w, 2/h) --
+// see div_by_recip() in gmpi_device.hpp.
 //
 // HBM traffic: each texel of the volume is read once per view (halo rows/columns are shared with the
 // neighbouring tiles through the XCD's L2: the blockIdx -> tile map gives every XCD a contiguous run
 // of tiles).  Algorithmic bytes: 16 B (fp32) / 8 B (bf16) per pixel*plane + 28-32 B per pixel.
 //
-// Planes whose box does not fit (texture much finer than the image, degenerate rays) fall back to
-// the direct gather for that plane only -- same arithmetic, so results do not depend on the path.
+// A chunk of planes in which some box exceeds the staging buffer (texture much finer than the image,
+// degenerate rays) takes the direct gather instead -- same arithmetic, so results do not depend on
+// the path.
 #include "gmpi_device.hpp"
+
+#include <cstdlib>
 
 namespace gmpi {
 
-constexpr int kTW = 64;               // tile width in pixels = lanes of a wavefront
-constexpr int kMaxQ = 18;             // 16-byte texel quads per staged row
-constexpr int kPitch = kMaxQ * 4;     // 72 floats per channel-row
-constexpr int kChunk = 128;           // planes per geometry-table refill
 constexpr int kNT = 512;              // threads per workgroup (8 wavefronts)
+constexpr int kChunk = 96;            // planes per geometry-table refill
+constexpr int kRecBytes = 48;         // per-plane record: three 16-byte LDS broadcasts
+constexpr int kCapFloats = 6144;      // staging buffer capacity (24 KB), two buffers
+constexpr int kCols = 16;             // loader lanes per box row = max quads per row (64 texels)
+constexpr int kRowcPerPass = kNT / kCols;  // (row,channel) lines covered by one loader pass
+constexpr int kNL = 4;                // loader passes -> at most 32 box rows
+constexpr int kMaxRows = kRowcPerPass * kNL / 4;
+constexpr int kInsideBit = 1 << 30;
 constexpr float kBoxEps = 1.0f / 64;  // slack on the corner-derived box (fp32 error of ix is < 1e-3 texel)
+constexpr int kLdsBytes = kChunk * kRecBytes + 2 * kCapFloats * 4;  // 53,760 B -> 3 workgroups per CU
 
-struct PlaneRec {  // 32 bytes, one per plane of the current chunk
-    int qx0, by0, nq, nrows;  // box origin (texels; qx0 multiple of 4), quads per row, rows; nq < 0: does not fit
-    float zdiff, ph, pw, pad;
-};
-
-template <int TH>
-struct Cfg {
-    static constexpr int kMaxR = TH + 3;                     // rows of the staged box
-    static constexpr int kItems = kMaxR * 4 * kMaxQ;          // float4 items per plane box
-    static constexpr int kNL = (kItems + kNT - 1) / kNT;      // items per thread
-    static constexpr int kTileFloats = kItems * 4;
-    static constexpr int kLdsBytes = kChunk * 32 + 2 * kTileFloats * 4;
-};
+// Per-plane record of the current chunk (LDS):
+//   tabI: qx0, by0 (box origin in texels, qx0 multiple of 4), nq (quads per row; < 0: box does not fit),
+//         nrows (| kInsideBit when the box lies completely inside the texture)
+//   tabF: zdiff = d - eye_z, hw = w/2, hh = h/2
+//   tabG: RN(1/hw), RN(1/hh), 64-bit element offset of the box origin inside the MPI volume
 
 // storage -> 4 floats ------------------------------------------------------------------------------------
 template <typename TexT> struct Quad;
@@ -77,17 +88,18 @@ __device__ __forceinline__ bool quad_out_of_unit(const float4& q) {
     return !(ok(a) && ok(b) && ok(c) && ok(d));
 }
 
-template <typename TexT, bool AC, bool STRICT, int TH, int PPT>
-__global__ __launch_bounds__(kNT) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y,
-                                                         const int n_tiles) {
-    using C = Cfg<TH>;
+// TW x TH pixel tile, one pixel per thread: lane = (x = tid % TW, y = tid / TW).
+template <typename TexT, bool AC, bool STRICT, int TW, int MINW>
+__global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y,
+                                                               const int n_tiles) {
     using Q = Quad<TexT>;
-    static_assert(kTW * TH / PPT == kNT, "tile / thread mismatch");
-    constexpr int kRowsPerPass = TH / PPT;
+    constexpr int TH = kNT / TW;
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[C::kLdsBytes];
-    PlaneRec* tab = reinterpret_cast<PlaneRec*>(smem);
-    float* tile0 = reinterpret_cast<float*>(smem + kChunk * 32);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
+    int4* tabI = reinterpret_cast<int4*>(smem);
+    float4* tabF = reinterpret_cast<float4*>(smem + kChunk * 16);
+    int4* tabG = reinterpret_cast<int4*>(smem + kChunk * 32);
+    float* tile0 = reinterpret_cast<float*>(smem + kChunk * kRecBytes);
 
     // ---- blockIdx -> tile: XCD x (blockIdx % 8) gets the contiguous run [x*per, (x+1)*per) of tiles, so
     //      neighbouring tiles (shared halo texels) meet in one L2 ------------------------------------------
@@ -100,7 +112,6 @@ __global__ __launch_bounds__(kNT) void render_lds_kernel(const KParams p, const 
     const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wrow = tid >> 6;
     const int m = p.view_to_mpi ? p.view_to_mpi[n] : n / p.views_per_mpi;
     const int D = p.D, Ht = p.Ht, Wt = p.Wt, H = p.H, W = p.W;
     const float* __restrict__ dhw = p.dhw + static_cast<int64_t>(m) * D * 3;
@@ -123,164 +134,190 @@ __global__ __launch_bounds__(kNT) void render_lds_kernel(const KParams p, const 
         if (behind) atomicOr(p.status, 4u);
     }
 
-    // ---- this thread's pixels (out-of-image lanes shadow the last row/column) --------------------------------
-    const int px = txi * kTW + lane;
-    const int pxc = min(px, W - 1);
-    float rx[PPT], ry[PPT], rz[PPT], dot[PPT];
-    int64_t pix[PPT];
-    bool active[PPT];
-    Accum A[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int py = tyi * TH + wrow + j * kRowsPerPass;
-        active[j] = px < W && py < H;
-        pix[j] = static_cast<int64_t>(min(py, H - 1)) * W + pxc;
-        rx[j] = rdv[pix[j]], ry[j] = rdv[HW + pix[j]], rz[j] = rdv[2 * HW + pix[j]];
-        float d = rx[j] * zx;  // einsum("nchw,nc->nhw") mpi.py:149
-        d = d + ry[j] * zy;
-        d = d + rz[j] * zz;
-        dot[j] = d;
-    }
+    // ---- this thread's pixel (out-of-image lanes shadow the last row/column) ---------------------------------
+    const int px = txi * TW + (tid % TW), py = tyi * TH + (tid / TW);
+    const bool active = px < W && py < H;
+    const int64_t pix = static_cast<int64_t>(min(py, H - 1)) * W + min(px, W - 1);
+    const float rx = rdv[pix], ry = rdv[HW + pix], rz = rdv[2 * HW + pix];
+    float dot = rx * zx;  // einsum("nchw,nc->nhw") mpi.py:149
+    dot = dot + ry * zy;
+    dot = dot + rz * zz;
+    const float rcp_rz = 1.0f / rz;  // correctly rounded; hoisted out of the plane loop (see div_by_recip)
+    Accum A;
 
-    // ---- tile corner rays (for the per-plane texel box) ------------------------------------------------------
-    const int cx0 = txi * kTW, cx1 = min(cx0 + kTW - 1, W - 1);
+    // ---- tile corner pixels (for the per-plane texel box) ----------------------------------------------------
+    const int cx0 = txi * TW, cx1 = min(cx0 + TW - 1, W - 1);
     const int cy0 = tyi * TH, cy1 = min(cy0 + TH - 1, H - 1);
 
-    // ---- loader role: item i = tid + r*kNT  <->  float4 slot i of the box = (row, channel, quad) -------------
-    uint32_t g_off[C::kNL];  // element offset of the item inside a plane, relative to the box origin
-    int it_row[C::kNL], it_col[C::kNL];
+    // ---- loader role: thread -> quad column `lcol` of (row,channel) lines lrowc + 32*r ------------------------
+    const int lcol = tid % kCols, lrowc = tid / kCols;
+    uint32_t g_off[kNL];  // element offset of item r inside a plane, relative to the box origin
 #pragma unroll
-    for (int r = 0; r < C::kNL; ++r) {
-        const int i = tid + r * kNT;
-        const int rowc = i / kMaxQ;
-        it_col[r] = i - rowc * kMaxQ;
-        it_row[r] = rowc >> 2;
-        const int c = rowc & 3;
-        g_off[r] = static_cast<uint32_t>(c * s_chan + it_row[r] * s_row + 4 * it_col[r]);
-        if (i >= C::kItems) it_row[r] = 1 << 20;  // never valid
+    for (int r = 0; r < kNL; ++r) {
+        const int rowc = lrowc + r * kRowcPerPass;
+        g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + 4 * lcol);
     }
-    typename Q::raw L[C::kNL];
+    typename Q::raw L[kNL];
 
     for (int kc = 0; kc < D; kc += kChunk) {
         const int kn = min(kChunk, D - kc);
         __syncthreads();  // previous chunk's table / tiles are no longer read
         // ---- per-plane geometry: texel box of this tile from its 4 corner pixels ---------------------------
+        bool unfit = false;
         for (int t = tid; t < kn; t += kNT) {
             const int k = kc + t;
-            PlaneRec rec;
-            const float d = dhw[3 * k + 0];
-            rec.ph = dhw[3 * k + 1], rec.pw = dhw[3 * k + 2];
-            rec.zdiff = d - ez;
-            rec.pad = 0.f;
+            const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
+            const float zdiff = d - ez;
             float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
             bool finite = true;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int64_t q = static_cast<int64_t>((c & 2) ? cy1 : cy0) * W + ((c & 1) ? cx1 : cx0);
                 float ix, iy, s, u, v;
-                plane_coord<AC>(rec.zdiff, rec.ph, rec.pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, s, u, v);
+                plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, s, u, v);
                 finite = finite && (fabsf(ix) < 1e6f) && (fabsf(iy) < 1e6f);  // false for NaN too
                 mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
             }
+            int4 ri = make_int4(0, 0, -1, 0);
             if (finite) {
                 const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
                 const int by0 = static_cast<int>(floorf(mny - kBoxEps)), by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
-                rec.qx0 = bx0 & ~3;
-                rec.by0 = by0;
-                rec.nq = ((bx1 - rec.qx0) >> 2) + 1;
-                rec.nrows = by1 - by0 + 1;
-                if (rec.nq > kMaxQ || rec.nrows > C::kMaxR) rec.nq = -1;
-            } else {
-                rec.qx0 = rec.by0 = rec.nrows = 0;
-                rec.nq = -1;
+                ri.x = bx0 & ~3;
+                ri.y = by0;
+                ri.z = ((bx1 - ri.x) >> 2) + 1;
+                ri.w = by1 - by0 + 1;
+                if (ri.z > kCols || ri.w > kMaxRows || ri.z * ri.w * 16 > kCapFloats) ri.z = -1;
+                else if (ri.x >= 0 && by0 >= 0 && ri.x + 4 * ri.z <= Wt && by0 + ri.w <= Ht) ri.w |= kInsideBit;
             }
-            tab[t] = rec;
+            unfit |= ri.z < 0;
+            const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
+            const int64_t goff = static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(ri.y) * s_row + ri.x;
+            tabI[t] = ri;
+            tabF[t] = make_float4(zdiff, hw, hh, 0.f);
+            tabG[t] = make_int4(__float_as_int(1.0f / hw), __float_as_int(1.0f / hh), static_cast<int>(goff & 0xffffffff),
+                                static_cast<int>(goff >> 32));
         }
-        __syncthreads();
+        const bool chunk_unfit = __syncthreads_or(unfit);  // also publishes the table
+
+        if (chunk_unfit) {
+            // ---- some box of this chunk exceeds the staging buffer: the whole chunk takes the direct gather
+            for (int t = 0; t < kn; ++t) {
+                const float4 rf = tabF[t];
+                float ix, iy, s, u, v;
+                plane_coord<AC>(rf.x, rf.z + rf.z, rf.y + rf.y, ex, ey, rx, ry, rz, cx, cy, ix, iy, s, u, v);
+                float smp[4];
+                gather_sample<TexT, STRICT>(vol + static_cast<int64_t>(kc + t) * s_plane, s_chan, s_row, Ht, Wt, ix, iy,
+                                            check_range, bad, smp);
+                blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
+            }
+            continue;
+        }
 
         // ---- register staging of one plane's box --------------------------------------------------------------
         auto issue_loads = [&](int t) {
-            const int qx0 = __builtin_amdgcn_readfirstlane(tab[t].qx0), by0 = __builtin_amdgcn_readfirstlane(tab[t].by0);
-            const int nq = __builtin_amdgcn_readfirstlane(tab[t].nq), nrows = __builtin_amdgcn_readfirstlane(tab[t].nrows);
-            if (nq < 0) return;
-            const TexT* __restrict__ base = vol + (static_cast<int64_t>(kc + t) * s_plane + static_cast<int64_t>(by0) * s_row + qx0);
+            const int4 ri = tabI[t];
+            const int4 rg = tabG[t];
+            const int nq = __builtin_amdgcn_readfirstlane(ri.z), nrw = __builtin_amdgcn_readfirstlane(ri.w);
+            const int64_t goff = (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(rg.w)) << 32) |
+                                 static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rg.z));
+            const TexT* __restrict__ base = vol + goff;
+            const int nrowc = (nrw & ~kInsideBit) * 4;
+            if (nrw & kInsideBit) {  // box inside the texture: no bounds tests
+                if (lcol < nq) {
 #pragma unroll
-            for (int r = 0; r < C::kNL; ++r) {
-                const bool in_box = it_row[r] < nrows && it_col[r] < nq;
-                const bool in_tex = static_cast<unsigned>(by0 + it_row[r]) < static_cast<unsigned>(Ht) &&
-                                    static_cast<unsigned>(qx0 + 4 * it_col[r]) < static_cast<unsigned>(Wt);
-                L[r] = Q::zero();
-                if (in_box && in_tex) L[r] = *reinterpret_cast<const typename Q::raw*>(base + g_off[r]);
+                    for (int r = 0; r < kNL; ++r)
+                        if (lrowc + r * kRowcPerPass < nrowc) L[r] = *reinterpret_cast<const typename Q::raw*>(base + g_off[r]);
+                }
+            } else {
+                const int qx0 = __builtin_amdgcn_readfirstlane(ri.x), by0 = __builtin_amdgcn_readfirstlane(ri.y);
+                const bool col_ok = lcol < nq && static_cast<unsigned>(qx0 + 4 * lcol) < static_cast<unsigned>(Wt);
+#pragma unroll
+                for (int r = 0; r < kNL; ++r) {
+                    const int rowc = lrowc + r * kRowcPerPass;
+                    L[r] = Q::zero();
+                    if (col_ok && rowc < nrowc && static_cast<unsigned>(by0 + (rowc >> 2)) < static_cast<unsigned>(Ht))
+                        L[r] = *reinterpret_cast<const typename Q::raw*>(base + g_off[r]);
+                }
             }
         };
         auto store_box = [&](int t, float* tile) {
-            const int nq = __builtin_amdgcn_readfirstlane(tab[t].nq), nrows = __builtin_amdgcn_readfirstlane(tab[t].nrows);
-            if (nq < 0) return;
+            const int4 ri = tabI[t];
+            const int nq = __builtin_amdgcn_readfirstlane(ri.z);
+            const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & ~kInsideBit) * 4;
+            if (lcol < nq) {
+                float4* dst = reinterpret_cast<float4*>(tile) + (lrowc * nq + lcol);  // pitch = nq quads
 #pragma unroll
-            for (int r = 0; r < C::kNL; ++r) {
-                if (it_row[r] < nrows && it_col[r] < nq) {
-                    const float4 q = Q::cvt(L[r]);
-                    if (check_range && quad_out_of_unit(q)) bad |= 2u;
-                    reinterpret_cast<float4*>(tile)[tid + r * kNT] = q;
+                for (int r = 0; r < kNL; ++r) {
+                    if (lrowc + r * kRowcPerPass < nrowc) {
+                        const float4 q = Q::cvt(L[r]);
+                        if (check_range && quad_out_of_unit(q)) bad |= 2u;
+                        dst[r * kRowcPerPass * nq] = q;
+                    }
                 }
             }
         };
 
         issue_loads(0);
         for (int t = 0; t < kn; ++t) {
-            float* tile = tile0 + (t & 1) * C::kTileFloats;
+            float* tile = tile0 + (t & 1) * kCapFloats;
             store_box(t, tile);
             __syncthreads();  // box t visible; everybody is done reading box t-1 (other buffer is free for t+1)
             if (t + 1 < kn) issue_loads(t + 1);  // in flight while box t is composited
 
-            const PlaneRec rec = tab[t];
-            const bool last = (kc + t == D - 1);
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                float ix, iy, s, u, v;
-                plane_coord<AC>(rec.zdiff, rec.ph, rec.pw, ex, ey, rx[j], ry[j], rz[j], cx, cy, ix, iy, s, u, v);
-                if (check_last && last && !(u >= -1.0f && u <= 1.0f && v >= -1.0f && v <= 1.0f)) bad |= 1u;
-                float smp[4];
-                if (rec.nq >= 0) {
-                    const Footprint f = footprint(ix, iy, Ht, Wt);
-                    // box-relative corner; the box contains every tap of the tile, the clamp only keeps wild
-                    // coordinates (NaN rays) inside the buffer.  (f.x0/f.y0 carry the gather path's -2
-                    // out-of-range sentinel, so the integer corner is re-derived from the floor here.)
-                    const int lx = min(max(static_cast<int>(floorf(ix)) - rec.qx0, 0), kPitch - 2);
-                    const int ly = min(max(static_cast<int>(floorf(iy)) - rec.by0, 0), C::kMaxR - 2);
-                    const float* __restrict__ t0 = tile + (ly * 4) * kPitch + lx;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float t_nw = t0[c * kPitch], t_ne = t0[c * kPitch + 1];
-                        const float t_sw = t0[(4 + c) * kPitch], t_se = t0[(4 + c) * kPitch + 1];
-                        smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
-                    }
-                } else {
-                    gather_sample<TexT, STRICT>(vol + static_cast<int64_t>(kc + t) * s_plane, s_chan, s_row, Ht, Wt, ix, iy,
-                                                check_range, bad, smp);
-                }
-                blend<STRICT>(A[j], smp[0], smp[1], smp[2], smp[3], s, dot[j]);
+            const int4 ri = tabI[t];
+            const float4 rf = tabF[t];
+            const int4 rg = tabG[t];
+            const int P = ri.z * 4;  // floats per (row,channel) line
+            float ix, iy, s;
+            Footprint f;
+            if (STRICT) {
+                float u, v;
+                plane_coord<AC>(rf.x, rf.z + rf.z, rf.y + rf.y, ex, ey, rx, ry, rz, cx, cy, ix, iy, s, u, v);
+                f = footprint(ix, iy, Ht, Wt);
+            } else {
+                plane_coord_recip<AC>(rf.x, rf.y, rf.z, __int_as_float(rg.x), __int_as_float(rg.y), ex, ey, rx, ry, rz, rcp_rz, cx,
+                                      cy, ix, iy, s);
+                // ATen's vectorised CPU form of the weights: e = 1 - w (equals x1 - ix unless ix < 0)
+                const float wx1 = ix - floorf(ix), wy1 = iy - floorf(iy);
+                const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+                f.nw = wx0 * wy0, f.ne = wx1 * wy0, f.sw = wx0 * wy1, f.se = wx1 * wy1;
             }
+            // the box contains every tap of the tile (corner argument above); the integer corner is taken from the
+            // floor directly (Footprint::x0/y0 carry the gather path's out-of-range sentinel)
+            const int lx = static_cast<int>(floorf(ix)) - ri.x, ly = static_cast<int>(floorf(iy)) - ri.y;
+            const float* __restrict__ t0 = tile + (ly * 4 * P + lx);
+            float smp[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float t_nw = t0[c * P], t_ne = t0[c * P + 1];
+                const float t_sw = t0[(4 + c) * P], t_se = t0[(4 + c) * P + 1];
+                smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
+            }
+            blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
         }
     }
 
-    const bool pm1 = (p.flags & (1u << 1)) != 0;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        float r = A[j].r, g = A[j].g, b = A[j].b;
-        if (pm1) {  // mpi_renderer.py:467  2*c - 1
-            r = 2.0f * r - 1.0f;
-            g = 2.0f * g - 1.0f;
-            b = 2.0f * b - 1.0f;
-        }
-        if (active[j]) {
-            float* __restrict__ out = p.rgb_out + static_cast<int64_t>(n) * 3 * HW + pix[j];
-            out[0] = r;
-            out[HW] = g;
-            out[2 * HW] = b;
-            p.depth_out[static_cast<int64_t>(n) * HW + pix[j]] = A[j].z;
-            if (p.T_out) p.T_out[static_cast<int64_t>(n) * HW + pix[j]] = A[j].T;
-        }
+    // ---- assert_not_out_of_last_plane (mpi.py:381-395): u,v of the last plane, once per pixel ------------------
+    if (check_last) {
+        const float d = dhw[3 * (D - 1) + 0], ph = dhw[3 * (D - 1) + 1], pw = dhw[3 * (D - 1) + 2];
+        float ix, iy, s, u, v;
+        plane_coord<AC>(d - ez, ph, pw, ex, ey, rx, ry, rz, cx, cy, ix, iy, s, u, v);
+        if (!(u >= -1.0f && u <= 1.0f && v >= -1.0f && v <= 1.0f)) bad |= 1u;
+    }
+
+    float r = A.r, g = A.g, b = A.b;
+    if (p.flags & (1u << 1)) {  // mpi_renderer.py:467  2*c - 1
+        r = 2.0f * r - 1.0f;
+        g = 2.0f * g - 1.0f;
+        b = 2.0f * b - 1.0f;
+    }
+    if (active) {
+        float* __restrict__ out = p.rgb_out + static_cast<int64_t>(n) * 3 * HW + pix;
+        out[0] = r;
+        out[HW] = g;
+        out[2 * HW] = b;
+        p.depth_out[static_cast<int64_t>(n) * HW + pix] = finish_depth<STRICT>(A, dot);
+        if (p.T_out) p.T_out[static_cast<int64_t>(n) * HW + pix] = A.T;
     }
     report_status(p.status, bad);
 }
@@ -295,39 +332,49 @@ bool lds_variant_supports(const KParams& p, int dtype) {
     if (reinterpret_cast<uintptr_t>(p.rgba) % quad_bytes != 0) return false;
     if (p.s_row % 4 != 0 || p.s_chan % 4 != 0 || p.s_plane % 4 != 0 || p.s_mpi % 4 != 0) return false;
     // the in-plane item offset is kept in 32 bits
-    const int64_t span = 3 * p.s_chan + 32 * p.s_row + 128;
+    const int64_t span = 3 * p.s_chan + (kMaxRows + 1) * p.s_row + 128;
     if (span >= (int64_t(1) << 31) / es) return false;
     return true;
 }
 
+constexpr int kTileW = 32;
+
 int lds_variant_query(int what) {
     switch (what) {
-        case 3: return Cfg<16>::kLdsBytes;
-        case 4: return kTW;
-        case 5: return 16;
+        case 3: return kLdsBytes;
+        case 4: return kTileW;
+        case 5: return kNT / kTileW;
         default: return -1;
     }
 }
 
-template <typename TexT, int TH, int PPT>
+template <typename TexT, int TW, int MINW>
 static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
-    const int tiles_x = (p.W + kTW - 1) / kTW, tiles_y = (p.H + TH - 1) / TH;
+    constexpr int TH = kNT / TW;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int n_tiles = tiles_x * tiles_y * p.N;
     const dim3 grid(((n_tiles + 7) / 8) * 8), block(kNT);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
-    if (ac && strict) hipLaunchKernelGGL((render_lds_kernel<TexT, true, true, TH, PPT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (ac) hipLaunchKernelGGL((render_lds_kernel<TexT, true, false, TH, PPT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (strict) hipLaunchKernelGGL((render_lds_kernel<TexT, false, true, TH, PPT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else hipLaunchKernelGGL((render_lds_kernel<TexT, false, false, TH, PPT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    if (ac && strict) hipLaunchKernelGGL((render_lds_kernel<TexT, true, true, TW, MINW>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else if (ac) hipLaunchKernelGGL((render_lds_kernel<TexT, true, false, TW, MINW>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else if (strict) hipLaunchKernelGGL((render_lds_kernel<TexT, false, true, TW, MINW>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else hipLaunchKernelGGL((render_lds_kernel<TexT, false, false, TW, MINW>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
     return hipGetLastError();
 }
 
-hipError_t launch_lds(const KParams& p, int dtype, hipStream_t stream) {
+template <int MINW>
+static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) {
     switch (dtype) {
-        case 0: return launch_lds_t<float, 16, 2>(p, stream);
-        case 1: return launch_lds_t<bf16_t, 16, 2>(p, stream);
-        default: return launch_lds_t<f16_t, 16, 2>(p, stream);
+        case 0: return launch_lds_t<float, kTileW, MINW>(p, stream);
+        case 1: return launch_lds_t<bf16_t, kTileW, MINW>(p, stream);
+        default: return launch_lds_t<f16_t, kTileW, MINW>(p, stream);
     }
+}
+
+hipError_t launch_lds(const KParams& p, int dtype, hipStream_t stream) {
+    static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 4; }();  // experiment knob
+    if (tune == 6) return launch_lds_w<6>(p, dtype, stream);
+    return launch_lds_w<4>(p, dtype, stream);
 }
 
 }  // namespace gmpi
