@@ -151,13 +151,13 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
 
     // ---- loader role: thread -> quad column `lcol` of (row,channel) lines lrowc + 32*r ------------------------
     const int lcol = tid % kCols, lrowc = tid / kCols;
-    uint32_t g_off[kNL];  // element offset of item r inside a plane, relative to the box origin
+    uint32_t g_off[kNL];  // BYTE offset of item r inside a plane, relative to the box origin (32-bit: saddr + voffset loads)
 #pragma unroll
     for (int r = 0; r < kNL; ++r) {
         const int rowc = lrowc + r * kRowcPerPass;
-        g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + 4 * lcol);
+        g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + 4 * lcol) * static_cast<uint32_t>(sizeof(TexT));
     }
-    typename Q::raw L[kNL];
+    typename Q::raw L0[kNL], L1[kNL];  // two staging register sets: loads run two planes ahead of the compositor
 
     for (int kc = 0; kc < D; kc += kChunk) {
         const int kn = min(kChunk, D - kc);
@@ -213,57 +213,57 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             continue;
         }
 
-        // ---- register staging of one plane's box --------------------------------------------------------------
-        auto issue_loads = [&](int t) {
+        // ---- register staging of one plane's box: branch-free raw buffer loads --------------------------------
+        // One buffer resource per plane (its 4 channel images); items that fall outside the box or outside the
+        // texture get the offset 0x80000000, which the hardware range check turns into zeros without touching
+        // memory -- no exec masking, loads issue back to back and stay two planes ahead.
+        const uint32_t plane_bytes = static_cast<uint32_t>((3 * s_chan + static_cast<int64_t>(Ht - 1) * s_row + Wt) * sizeof(TexT));
+        auto issue_loads = [&](int t, typename Q::raw (&L)[kNL]) {
+            if (t >= kn) return;
             const int4 ri = tabI[t];
-            const int4 rg = tabG[t];
+            const int qx0 = __builtin_amdgcn_readfirstlane(ri.x), by0 = __builtin_amdgcn_readfirstlane(ri.y);
             const int nq = __builtin_amdgcn_readfirstlane(ri.z), nrw = __builtin_amdgcn_readfirstlane(ri.w);
-            const int64_t goff = (static_cast<int64_t>(__builtin_amdgcn_readfirstlane(rg.w)) << 32) |
-                                 static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rg.z));
-            const TexT* __restrict__ base = vol + goff;
+            // the descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a waterfall loop
+            // (cdna_hip_programming.md T20): pass its inputs through readfirstlane
+            const uint64_t pa = reinterpret_cast<uint64_t>(vol + static_cast<int64_t>(kc + t) * s_plane);
+            const uint32_t pa_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pa >> 32)));
+            const uint32_t pa_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pa & 0xffffffffu)));
+            const uint64_t pu = (static_cast<uint64_t>(pa_hi) << 32) | pa_lo;  // (readfirstlane returns int: widen unsigned)
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void*>(pu), 0, __builtin_amdgcn_readfirstlane(static_cast<int>(plane_bytes)), 0x00020000);
+            const uint32_t origin = static_cast<uint32_t>(by0 * static_cast<int>(s_row) + qx0) * static_cast<uint32_t>(sizeof(TexT));
             const int nrowc = (nrw & ~kInsideBit) * 4;
-            if (nrw & kInsideBit) {  // box inside the texture: no bounds tests
-                if (lcol < nq) {
+            bool col_ok = lcol < nq;
+            if (!(nrw & kInsideBit)) col_ok = col_ok && static_cast<unsigned>(qx0 + 4 * lcol) < static_cast<unsigned>(Wt);
 #pragma unroll
-                    for (int r = 0; r < kNL; ++r)
-                        if (lrowc + r * kRowcPerPass < nrowc) L[r] = *reinterpret_cast<const typename Q::raw*>(base + g_off[r]);
-                }
-            } else {
-                const int qx0 = __builtin_amdgcn_readfirstlane(ri.x), by0 = __builtin_amdgcn_readfirstlane(ri.y);
-                const bool col_ok = lcol < nq && static_cast<unsigned>(qx0 + 4 * lcol) < static_cast<unsigned>(Wt);
-#pragma unroll
-                for (int r = 0; r < kNL; ++r) {
-                    const int rowc = lrowc + r * kRowcPerPass;
-                    L[r] = Q::zero();
-                    if (col_ok && rowc < nrowc && static_cast<unsigned>(by0 + (rowc >> 2)) < static_cast<unsigned>(Ht))
-                        L[r] = *reinterpret_cast<const typename Q::raw*>(base + g_off[r]);
+            for (int r = 0; r < kNL; ++r) {
+                const int rowc = lrowc + r * kRowcPerPass;
+                bool ok = col_ok && rowc < nrowc;
+                if (!(nrw & kInsideBit)) ok = ok && static_cast<unsigned>(by0 + (rowc >> 2)) < static_cast<unsigned>(Ht);
+                const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;  // >= num_records (< 2^31), and off+15 cannot wrap
+                if constexpr (sizeof(typename Q::raw) == 16) {
+                    L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                } else {
+                    L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
                 }
             }
         };
-        auto store_box = [&](int t, float* tile) {
+        auto store_box = [&](int t, float* tile, typename Q::raw (&L)[kNL]) {
             const int4 ri = tabI[t];
             const int nq = __builtin_amdgcn_readfirstlane(ri.z);
             const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & ~kInsideBit) * 4;
-            if (lcol < nq) {
-                float4* dst = reinterpret_cast<float4*>(tile) + (lrowc * nq + lcol);  // pitch = nq quads
+            float4* dst = reinterpret_cast<float4*>(tile) + (__umul24(lrowc, nq) + lcol);  // pitch = nq quads
+            const int step = kRowcPerPass * nq;
+            const bool col_ok = lcol < nq;
 #pragma unroll
-                for (int r = 0; r < kNL; ++r) {
-                    if (lrowc + r * kRowcPerPass < nrowc) {
-                        const float4 q = Q::cvt(L[r]);
-                        if (check_range && quad_out_of_unit(q)) bad |= 2u;
-                        dst[r * kRowcPerPass * nq] = q;
-                    }
-                }
+            for (int r = 0; r < kNL; ++r) {
+                const float4 q = Q::cvt(L[r]);
+                if (check_range && quad_out_of_unit(q)) bad |= 2u;  // lanes outside the box hold zeros
+                if (col_ok && lrowc + r * kRowcPerPass < nrowc) dst[r * step] = q;
             }
         };
 
-        issue_loads(0);
-        for (int t = 0; t < kn; ++t) {
-            float* tile = tile0 + (t & 1) * kCapFloats;
-            store_box(t, tile);
-            __syncthreads();  // box t visible; everybody is done reading box t-1 (other buffer is free for t+1)
-            if (t + 1 < kn) issue_loads(t + 1);  // in flight while box t is composited
-
+        auto composite = [&](int t, const float* __restrict__ tile) {
             const int4 ri = tabI[t];
             const float4 rf = tabF[t];
             const int4 rg = tabG[t];
@@ -294,6 +294,20 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
             }
             blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
+        };
+        issue_loads(0, L0);
+        issue_loads(1, L1);
+        for (int t = 0; t < kn; t += 2) {
+            store_box(t, tile0, L0);
+            __syncthreads();  // box t visible; everybody is done reading box t-2 (same buffer) and t-1
+            issue_loads(t + 2, L0);  // two planes ahead, in flight while boxes t and t+1 are composited
+            composite(t, tile0);
+            if (t + 1 < kn) {
+                store_box(t + 1, tile0 + kCapFloats, L1);
+                __syncthreads();
+                issue_loads(t + 3, L1);
+                composite(t + 1, tile0 + kCapFloats);
+            }
         }
     }
 
