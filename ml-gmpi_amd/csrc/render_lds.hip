@@ -38,14 +38,15 @@ namespace gmpi {
 constexpr int kNT = 512;              // threads per workgroup (8 wavefronts)
 constexpr int kChunk = 96;            // planes per geometry-table refill
 constexpr int kRecBytes = 48;         // per-plane record: three 16-byte LDS broadcasts
-constexpr int kCapFloats = 6144;      // staging buffer capacity (24 KB), two buffers
-constexpr int kCols = 16;             // loader lanes per box row = max quads per row (64 texels)
-constexpr int kRowcPerPass = kNT / kCols;  // (row,channel) lines covered by one loader pass
-constexpr int kNL = 4;                // loader passes -> at most 32 box rows
+constexpr int kCols = 13;             // loader lanes per box line = max quads per row (52 texels)
+constexpr int kPitch = kCols * 4;     // floats per (row,channel) line in LDS (fixed)
+constexpr int kRowcPerPass = kNT / kCols;  // 39 (row,channel) lines per loader pass (507 loader threads)
+constexpr int kNL = 3;                // loader passes -> 117 lines = 29 box rows
 constexpr int kMaxRows = kRowcPerPass * kNL / 4;
+constexpr int kCapFloats = kRowcPerPass * kNL * kPitch;  // 6084 floats (24.3 KB) per staging buffer, two buffers
 constexpr int kInsideBit = 1 << 30;
 constexpr float kBoxEps = 1.0f / 64;  // slack on the corner-derived box (fp32 error of ix is < 1e-3 texel)
-constexpr int kLdsBytes = kChunk * kRecBytes + 2 * kCapFloats * 4;  // 53,760 B -> 3 workgroups per CU
+constexpr int kLdsBytes = kChunk * kRecBytes + 2 * kCapFloats * 4;  // 53,280 B -> 3 workgroups per CU
 
 // Per-plane record of the current chunk (LDS):
 //   tabI: qx0, by0 (box origin in texels, qx0 multiple of 4), nq (quads per row; < 0: box does not fit),
@@ -149,9 +150,10 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     const int cx0 = txi * TW, cx1 = min(cx0 + TW - 1, W - 1);
     const int cy0 = tyi * TH, cy1 = min(cy0 + TH - 1, H - 1);
 
-    // ---- loader role: thread -> quad column `lcol` of (row,channel) lines lrowc + 32*r ------------------------
+    // ---- loader role: thread -> quad column `lcol` of (row,channel) lines lrowc + 39*r (threads 507..511 idle) ----
     const int lcol = tid % kCols, lrowc = tid / kCols;
-    uint32_t g_off[kNL];  // BYTE offset of item r inside a plane, relative to the box origin (32-bit: saddr + voffset loads)
+    const bool loader = tid < kRowcPerPass * kCols;
+    uint32_t g_off[kNL];  // BYTE offset of item r inside a plane, relative to the box origin (32-bit voffset)
 #pragma unroll
     for (int r = 0; r < kNL; ++r) {
         const int rowc = lrowc + r * kRowcPerPass;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 ri.y = by0;
                 ri.z = ((bx1 - ri.x) >> 2) + 1;
                 ri.w = by1 - by0 + 1;
-                if (ri.z > kCols || ri.w > kMaxRows || ri.z * ri.w * 16 > kCapFloats) ri.z = -1;
+                if (ri.z > kCols || ri.w > kMaxRows) ri.z = -1;
                 else if (ri.x >= 0 && by0 >= 0 && ri.x + 4 * ri.z <= Wt && by0 + ri.w <= Ht) ri.w |= kInsideBit;
             }
             unfit |= ri.z < 0;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 reinterpret_cast<void*>(pu), 0, __builtin_amdgcn_readfirstlane(static_cast<int>(plane_bytes)), 0x00020000);
             const uint32_t origin = static_cast<uint32_t>(by0 * static_cast<int>(s_row) + qx0) * static_cast<uint32_t>(sizeof(TexT));
             const int nrowc = (nrw & ~kInsideBit) * 4;
-            bool col_ok = lcol < nq;
+            bool col_ok = loader && lcol < nq;
             if (!(nrw & kInsideBit)) col_ok = col_ok && static_cast<unsigned>(qx0 + 4 * lcol) < static_cast<unsigned>(Wt);
 #pragma unroll
             for (int r = 0; r < kNL; ++r) {
@@ -252,14 +254,13 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             const int4 ri = tabI[t];
             const int nq = __builtin_amdgcn_readfirstlane(ri.z);
             const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & ~kInsideBit) * 4;
-            float4* dst = reinterpret_cast<float4*>(tile) + (__umul24(lrowc, nq) + lcol);  // pitch = nq quads
-            const int step = kRowcPerPass * nq;
-            const bool col_ok = lcol < nq;
+            float4* dst = reinterpret_cast<float4*>(tile) + tid;  // slot (lrowc + 39 r) * 13 + lcol == tid + 507 r
+            const bool col_ok = loader && lcol < nq;
 #pragma unroll
             for (int r = 0; r < kNL; ++r) {
                 const float4 q = Q::cvt(L[r]);
                 if (check_range && quad_out_of_unit(q)) bad |= 2u;  // lanes outside the box hold zeros
-                if (col_ok && lrowc + r * kRowcPerPass < nrowc) dst[r * step] = q;
+                if (col_ok && lrowc + r * kRowcPerPass < nrowc) dst[r * (kRowcPerPass * kCols)] = q;
             }
         };
 
@@ -267,7 +268,6 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             const int4 ri = tabI[t];
             const float4 rf = tabF[t];
             const int4 rg = tabG[t];
-            const int P = ri.z * 4;  // floats per (row,channel) line
             float ix, iy, s;
             Footprint f;
             if (STRICT) {
@@ -285,12 +285,15 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             // the box contains every tap of the tile (corner argument above); the integer corner is taken from the
             // floor directly (Footprint::x0/y0 carry the gather path's out-of-range sentinel)
             const int lx = static_cast<int>(floorf(ix)) - ri.x, ly = static_cast<int>(floorf(iy)) - ri.y;
-            const float* __restrict__ t0 = tile + (ly * 4 * P + lx);
+            // unsigned + clamped: keeps wild coordinates (NaN rays) inside the buffer and proves the base non-negative,
+            // so the 8 tap-pair reads become ds_read2_b32 with immediate offsets
+            const uint32_t idx = min(static_cast<uint32_t>(ly * (4 * kPitch) + lx), static_cast<uint32_t>(kCapFloats - 8 * kPitch));
+            const float* __restrict__ t0 = tile + idx;
             float smp[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float t_nw = t0[c * P], t_ne = t0[c * P + 1];
-                const float t_sw = t0[(4 + c) * P], t_se = t0[(4 + c) * P + 1];
+                const float t_nw = t0[c * kPitch], t_ne = t0[c * kPitch + 1];
+                const float t_sw = t0[(4 + c) * kPitch], t_se = t0[(4 + c) * kPitch + 1];
                 smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
             }
             blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
