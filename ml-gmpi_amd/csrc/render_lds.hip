@@ -389,9 +389,9 @@ static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) 
 }
 
 hipError_t launch_lds(const KParams& p, int dtype, hipStream_t stream) {
-    static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 4; }();  // experiment knob
-    if (tune == 6) return launch_lds_w<6>(p, dtype, stream);
-    return launch_lds_w<4>(p, dtype, stream);
+    static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 6; }();  // experiment knob (6 = three workgroups per CU)
+    if (tune == 4) return launch_lds_w<4>(p, dtype, stream);
+    return launch_lds_w<6>(p, dtype, stream);
 }
 
 }  // namespace gmpi
