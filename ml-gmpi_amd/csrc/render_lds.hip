@@ -38,10 +38,10 @@ namespace gmpi {
 constexpr int kNT = 512;              // threads per workgroup (8 wavefronts)
 constexpr int kChunk = 96;            // planes per geometry-table refill
 constexpr int kRecBytes = 48;         // per-plane record: three 16-byte LDS broadcasts
-constexpr int kCols = 13;             // loader lanes per box line = max quads per row (52 texels)
+constexpr int kCols = 14;             // loader lanes per box line = max quads per row (56 texels); pitch 56 floats keeps the row stride (4*56 floats) a multiple of the 32 LDS banks -> taps of lanes on neighbouring texel rows do not conflict
 constexpr int kPitch = kCols * 4;     // floats per (row,channel) line in LDS (fixed)
-constexpr int kRowcPerPass = kNT / kCols;  // 39 (row,channel) lines per loader pass (507 loader threads)
-constexpr int kNL = 3;                // loader passes -> 117 lines = 29 box rows
+constexpr int kRowcPerPass = kNT / kCols;  // 36 (row,channel) lines per loader pass (504 loader threads)
+constexpr int kNL = 3;                // loader passes -> 108 lines = 27 box rows
 constexpr int kMaxRows = kRowcPerPass * kNL / 4;
 constexpr int kCapFloats = kRowcPerPass * kNL * kPitch;  // 6084 floats (24.3 KB) per staging buffer, two buffers
 constexpr int kInsideBit = 1 << 30;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     const int cx0 = txi * TW, cx1 = min(cx0 + TW - 1, W - 1);
     const int cy0 = tyi * TH, cy1 = min(cy0 + TH - 1, H - 1);
 
-    // ---- loader role: thread -> quad column `lcol` of (row,channel) lines lrowc + 39*r (threads 507..511 idle) ----
+    // ---- loader role: thread -> quad column `lcol` of (row,channel) lines lrowc + 36*r (threads 504..511 idle) ----
     const int lcol = tid % kCols, lrowc = tid / kCols;
     const bool loader = tid < kRowcPerPass * kCols;
     uint32_t g_off[kNL];  // BYTE offset of item r inside a plane, relative to the box origin (32-bit voffset)
@@ -220,8 +220,9 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // texture get the offset 0x80000000, which the hardware range check turns into zeros without touching
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
         const uint32_t plane_bytes = static_cast<uint32_t>((3 * s_chan + static_cast<int64_t>(Ht - 1) * s_row + Wt) * sizeof(TexT));
+        // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
         auto issue_loads = [&](int t, typename Q::raw (&L)[kNL]) {
-            if (t >= kn) return;
+            if (t >= kn || (p.flags & (1u << 16))) return;
             const int4 ri = tabI[t];
             const int qx0 = __builtin_amdgcn_readfirstlane(ri.x), by0 = __builtin_amdgcn_readfirstlane(ri.y);
             const int nq = __builtin_amdgcn_readfirstlane(ri.z), nrw = __builtin_amdgcn_readfirstlane(ri.w);
@@ -235,36 +236,52 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 reinterpret_cast<void*>(pu), 0, __builtin_amdgcn_readfirstlane(static_cast<int>(plane_bytes)), 0x00020000);
             const uint32_t origin = static_cast<uint32_t>(by0 * static_cast<int>(s_row) + qx0) * static_cast<uint32_t>(sizeof(TexT));
             const int nrowc = (nrw & ~kInsideBit) * 4;
-            bool col_ok = loader && lcol < nq;
-            if (!(nrw & kInsideBit)) col_ok = col_ok && static_cast<unsigned>(qx0 + 4 * lcol) < static_cast<unsigned>(Wt);
+            if (nrw & kInsideBit) {  // box inside the texture (wave-uniform): no bounds tests
+                const bool col_ok = loader & (lcol < nq);
 #pragma unroll
-            for (int r = 0; r < kNL; ++r) {
-                const int rowc = lrowc + r * kRowcPerPass;
-                bool ok = col_ok && rowc < nrowc;
-                if (!(nrw & kInsideBit)) ok = ok && static_cast<unsigned>(by0 + (rowc >> 2)) < static_cast<unsigned>(Ht);
-                const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;  // >= num_records (< 2^31), and off+15 cannot wrap
-                if constexpr (sizeof(typename Q::raw) == 16) {
-                    L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-                } else {
-                    L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+                for (int r = 0; r < kNL; ++r) {
+                    const bool ok = col_ok & (lrowc + r * kRowcPerPass < nrowc);
+                    const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;  // >= num_records (< 2^31); off+15 cannot wrap
+                    if constexpr (sizeof(typename Q::raw) == 16) L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                    else L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+                }
+            } else {
+                const bool col_ok = loader & (lcol < nq) & (static_cast<unsigned>(qx0 + 4 * lcol) < static_cast<unsigned>(Wt));
+#pragma unroll
+                for (int r = 0; r < kNL; ++r) {
+                    const int rowc = lrowc + r * kRowcPerPass;
+                    const bool ok = col_ok & (rowc < nrowc) & (static_cast<unsigned>(by0 + (rowc >> 2)) < static_cast<unsigned>(Ht));
+                    const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;
+                    if constexpr (sizeof(typename Q::raw) == 16) L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                    else L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
                 }
             }
         };
         auto store_box = [&](int t, float* tile, typename Q::raw (&L)[kNL]) {
+            if (p.flags & (1u << 18)) return;
             const int4 ri = tabI[t];
             const int nq = __builtin_amdgcn_readfirstlane(ri.z);
             const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & ~kInsideBit) * 4;
-            float4* dst = reinterpret_cast<float4*>(tile) + tid;  // slot (lrowc + 39 r) * 13 + lcol == tid + 507 r
-            const bool col_ok = loader && lcol < nq;
+            float4* dst = reinterpret_cast<float4*>(tile) + tid;  // slot (lrowc + 36 r) * 14 + lcol == tid + 504 r
+            const bool col_ok = loader & (lcol < nq);
+            uint32_t mx = 0;  // max of the fp32 bit patterns staged by this lane (lanes outside the box hold zeros)
 #pragma unroll
             for (int r = 0; r < kNL; ++r) {
                 const float4 q = Q::cvt(L[r]);
-                if (check_range && quad_out_of_unit(q)) bad |= 2u;  // lanes outside the box hold zeros
-                if (col_ok && lrowc + r * kRowcPerPass < nrowc) dst[r * (kRowcPerPass * kCols)] = q;
+                mx = max(max(mx, __float_as_uint(q.x)), max(max(__float_as_uint(q.y), __float_as_uint(q.z)), __float_as_uint(q.w)));
+                if (col_ok & (lrowc + r * kRowcPerPass < nrowc)) dst[r * (kRowcPerPass * kCols)] = q;
+            }
+            // [0,1] test on bit patterns: non-negative floats order like unsigned ints, so v in [0,1] <=> bits <=
+            // 0x3f800000; negative values (sign bit) and NaN/Inf compare above.  -0.0 is legal: exact re-test (cold).
+            if (check_range && __builtin_expect(mx > 0x3f800000u, 0)) {
+#pragma unroll
+                for (int r = 0; r < kNL; ++r)
+                    if (quad_out_of_unit(Q::cvt(L[r]))) bad |= 2u;
             }
         };
 
         auto composite = [&](int t, const float* __restrict__ tile) {
+            if (p.flags & (1u << 17)) return;
             const int4 ri = tabI[t];
             const float4 rf = tabF[t];
             const int4 rg = tabG[t];
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             const int lx = static_cast<int>(floorf(ix)) - ri.x, ly = static_cast<int>(floorf(iy)) - ri.y;
             // unsigned + clamped: keeps wild coordinates (NaN rays) inside the buffer and proves the base non-negative,
             // so the 8 tap-pair reads become ds_read2_b32 with immediate offsets
-            const uint32_t idx = min(static_cast<uint32_t>(ly * (4 * kPitch) + lx), static_cast<uint32_t>(kCapFloats - 8 * kPitch));
+            const uint32_t idx = min(static_cast<uint32_t>(ly * (4 * kPitch) + lx), static_cast<uint32_t>(kCapFloats - 7 * kPitch - 2));
             const float* __restrict__ t0 = tile + idx;
             float smp[4];
 #pragma unroll
@@ -388,7 +405,10 @@ static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) 
     }
 }
 
-hipError_t launch_lds(const KParams& p, int dtype, hipStream_t stream) {
+hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
+    static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
+    KParams p = p0;
+    p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores
     static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 6; }();  // experiment knob (6 = three workgroups per CU)
     if (tune == 4) return launch_lds_w<4>(p, dtype, stream);
     return launch_lds_w<6>(p, dtype, stream);
