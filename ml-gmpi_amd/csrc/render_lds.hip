@@ -38,44 +38,54 @@ namespace gmpi {
 constexpr int kNT = 512;              // threads per workgroup (8 wavefronts)
 constexpr int kChunk = 96;            // planes per geometry-table refill
 constexpr int kRecBytes = 48;         // per-plane record: three 16-byte LDS broadcasts
-constexpr int kCols = 14;             // loader lanes per box line = max quads per row (56 texels); pitch 56 floats keeps the row stride (4*56 floats) a multiple of the 32 LDS banks -> taps of lanes on neighbouring texel rows do not conflict
-constexpr int kPitch = kCols * 4;     // floats per (row,channel) line in LDS (fixed)
-constexpr int kRowcPerPass = kNT / kCols;  // 36 (row,channel) lines per loader pass (504 loader threads)
-constexpr int kNL = 3;                // loader passes -> 108 lines = 27 box rows
-constexpr int kMaxRows = kRowcPerPass * kNL / 4;
-constexpr int kCapFloats = kRowcPerPass * kNL * kPitch;  // 6084 floats (24.3 KB) per staging buffer, two buffers
+constexpr int kPitch = 56;            // floats per (row,channel) line in LDS; the texel-row stride 4*56 floats is a multiple
+                                      // of the 32 LDS banks, so taps of lanes on neighbouring texel rows do not conflict
+constexpr int kMaxLines = 108;        // (row,channel) lines per staging buffer = 27 box rows
+constexpr int kMaxRows = kMaxLines / 4;
+constexpr int kCapFloats = kMaxLines * kPitch;  // 6048 floats (24.2 KB) per staging buffer, two buffers
 constexpr int kInsideBit = 1 << 30;
 constexpr float kBoxEps = 1.0f / 64;  // slack on the corner-derived box (fp32 error of ix is < 1e-3 texel)
-constexpr int kLdsBytes = kChunk * kRecBytes + 2 * kCapFloats * 4;  // 53,280 B -> 3 workgroups per CU
+constexpr int kLdsBytes = kChunk * kRecBytes + 2 * kCapFloats * 4;  // 52,992 B -> 3 workgroups per CU
+
+// Loader geometry: one item = 16 bytes of storage = TPI texels; a box line holds kPitch/TPI items.
+template <int TPI> struct LoaderCfg {
+    static constexpr int kCols = kPitch / TPI;                 // 14 (fp32) / 7 (16-bit) lanes per line
+    static constexpr int kLinesPerPass = kNT / kCols;            // 36 / 73 lines per pass
+    static constexpr int kNL = (kMaxLines + kLinesPerPass - 1) / kLinesPerPass;  // 3 / 2 passes
+    static constexpr int kLoaders = kLinesPerPass * kCols;       // 504 / 511 loader threads
+};
 
 // Per-plane record of the current chunk (LDS):
-//   tabI: qx0, by0 (box origin in texels, qx0 multiple of 4), nq (quads per row; < 0: box does not fit),
+//   tabI: qx0, by0 (box origin in texels, qx0 multiple of the item width), nq (items per row; < 0: box does not fit),
 //         nrows (| kInsideBit when the box lies completely inside the texture)
 //   tabF: zdiff = d - eye_z, hw = w/2, hh = h/2
 //   tabG: RN(1/hw), RN(1/hh), 64-bit element offset of the box origin inside the MPI volume
 
-// storage -> 4 floats ------------------------------------------------------------------------------------
+// storage -> fp32: one loader item is ALWAYS 16 bytes of storage (4 fp32 texels or 8 half-precision texels:
+// the load path is request-bound, so 16-bit volumes move twice the texels per request) -----------------------
 template <typename TexT> struct Quad;
 template <> struct Quad<float> {
-    using raw = float4;
-    static __device__ __forceinline__ raw zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-    static __device__ __forceinline__ float4 cvt(raw v) { return v; }
+    static constexpr int kTexels = 4;
+    static __device__ __forceinline__ void cvt(const uint4& v, float4 (&o)[1]) {
+        o[0] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
 };
 template <> struct Quad<bf16_t> {
-    using raw = uint2;
-    static __device__ __forceinline__ raw zero() { return make_uint2(0u, 0u); }
-    static __device__ __forceinline__ float4 cvt(raw v) {
-        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+    static constexpr int kTexels = 8;
+    static __device__ __forceinline__ void cvt(const uint4& v, float4 (&o)[2]) {
+        o[0] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
                            __uint_as_float(v.y & 0xffff0000u));
+        o[1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16),
+                           __uint_as_float(v.w & 0xffff0000u));
     }
 };
 template <> struct Quad<f16_t> {
-    using raw = uint2;
-    static __device__ __forceinline__ raw zero() { return make_uint2(0u, 0u); }
-    static __device__ __forceinline__ float4 cvt(raw v) {
+    static constexpr int kTexels = 8;
+    static __device__ __forceinline__ void cvt(const uint4& v, float4 (&o)[2]) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y);
-        return make_float4(static_cast<float>(a.x), static_cast<float>(a.y), static_cast<float>(b.x), static_cast<float>(b.y));
+        const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y), c = __builtin_bit_cast(h2, v.z), d = __builtin_bit_cast(h2, v.w);
+        o[0] = make_float4(static_cast<float>(a.x), static_cast<float>(a.y), static_cast<float>(b.x), static_cast<float>(b.y));
+        o[1] = make_float4(static_cast<float>(c.x), static_cast<float>(c.y), static_cast<float>(d.x), static_cast<float>(d.y));
     }
 };
 
@@ -94,6 +104,8 @@ template <typename TexT, bool AC, bool STRICT, int TW, int MINW>
 __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y,
                                                                const int n_tiles) {
     using Q = Quad<TexT>;
+    using LC = LoaderCfg<Q::kTexels>;
+    constexpr int TPI = Q::kTexels, kCols = LC::kCols, kRowcPerPass = LC::kLinesPerPass, kNL = LC::kNL;
     constexpr int TH = kNT / TW;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
@@ -150,16 +162,16 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     const int cx0 = txi * TW, cx1 = min(cx0 + TW - 1, W - 1);
     const int cy0 = tyi * TH, cy1 = min(cy0 + TH - 1, H - 1);
 
-    // ---- loader role: thread -> quad column `lcol` of (row,channel) lines lrowc + 36*r (threads 504..511 idle) ----
+    // ---- loader role: thread -> item column `lcol` of (row,channel) lines lrowc + kRowcPerPass*r ----------------
     const int lcol = tid % kCols, lrowc = tid / kCols;
-    const bool loader = tid < kRowcPerPass * kCols;
+    const bool loader = tid < LC::kLoaders;
     uint32_t g_off[kNL];  // BYTE offset of item r inside a plane, relative to the box origin (32-bit voffset)
 #pragma unroll
     for (int r = 0; r < kNL; ++r) {
         const int rowc = lrowc + r * kRowcPerPass;
-        g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + 4 * lcol) * static_cast<uint32_t>(sizeof(TexT));
+        g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) * static_cast<uint32_t>(sizeof(TexT));
     }
-    typename Q::raw L0[kNL], L1[kNL];  // two staging register sets: loads run two planes ahead of the compositor
+    uint4 L0[kNL], L1[kNL];  // two staging register sets: loads run two planes ahead of the compositor
 
     for (int kc = 0; kc < D; kc += kChunk) {
         const int kn = min(kChunk, D - kc);
@@ -184,12 +196,12 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             if (finite) {
                 const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
                 const int by0 = static_cast<int>(floorf(mny - kBoxEps)), by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
-                ri.x = bx0 & ~3;
+                ri.x = bx0 & ~(TPI - 1);
                 ri.y = by0;
-                ri.z = ((bx1 - ri.x) >> 2) + 1;
+                ri.z = (bx1 - ri.x) / TPI + 1;
                 ri.w = by1 - by0 + 1;
                 if (ri.z > kCols || ri.w > kMaxRows) ri.z = -1;
-                else if (ri.x >= 0 && by0 >= 0 && ri.x + 4 * ri.z <= Wt && by0 + ri.w <= Ht) ri.w |= kInsideBit;
+                else if (ri.x >= 0 && by0 >= 0 && ri.x + TPI * ri.z <= Wt && by0 + ri.w <= Ht) ri.w |= kInsideBit;
             }
             unfit |= ri.z < 0;
             const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
         const uint32_t plane_bytes = static_cast<uint32_t>((3 * s_chan + static_cast<int64_t>(Ht - 1) * s_row + Wt) * sizeof(TexT));
         // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
-        auto issue_loads = [&](int t, typename Q::raw (&L)[kNL]) {
+        auto issue_loads = [&](int t, uint4 (&L)[kNL]) {
             if (t >= kn || (p.flags & (1u << 16))) return;
             const int4 ri = tabI[t];
             const int qx0 = __builtin_amdgcn_readfirstlane(ri.x), by0 = __builtin_amdgcn_readfirstlane(ri.y);
@@ -242,41 +254,50 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 for (int r = 0; r < kNL; ++r) {
                     const bool ok = col_ok & (lrowc + r * kRowcPerPass < nrowc);
                     const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;  // >= num_records (< 2^31); off+15 cannot wrap
-                    if constexpr (sizeof(typename Q::raw) == 16) L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-                    else L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+                    L[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
                 }
             } else {
-                const bool col_ok = loader & (lcol < nq) & (static_cast<unsigned>(qx0 + 4 * lcol) < static_cast<unsigned>(Wt));
+                const bool col_ok = loader & (lcol < nq) & (static_cast<unsigned>(qx0 + TPI * lcol) < static_cast<unsigned>(Wt));
 #pragma unroll
                 for (int r = 0; r < kNL; ++r) {
                     const int rowc = lrowc + r * kRowcPerPass;
                     const bool ok = col_ok & (rowc < nrowc) & (static_cast<unsigned>(by0 + (rowc >> 2)) < static_cast<unsigned>(Ht));
                     const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;
-                    if constexpr (sizeof(typename Q::raw) == 16) L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-                    else L[r] = __builtin_bit_cast(typename Q::raw, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+                    L[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
                 }
             }
         };
-        auto store_box = [&](int t, float* tile, typename Q::raw (&L)[kNL]) {
+        auto store_box = [&](int t, float* tile, uint4 (&L)[kNL]) {
             if (p.flags & (1u << 18)) return;
             const int4 ri = tabI[t];
             const int nq = __builtin_amdgcn_readfirstlane(ri.z);
             const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & ~kInsideBit) * 4;
-            float4* dst = reinterpret_cast<float4*>(tile) + tid;  // slot (lrowc + 36 r) * 14 + lcol == tid + 504 r
+            // LDS slot of item r: line (lrowc + kRowcPerPass*r), floats [TPI*lcol, TPI*lcol + TPI)
+            float4* dst = reinterpret_cast<float4*>(tile) + (lrowc * (kPitch / 4) + lcol * (TPI / 4));
             const bool col_ok = loader & (lcol < nq);
             uint32_t mx = 0;  // max of the fp32 bit patterns staged by this lane (lanes outside the box hold zeros)
 #pragma unroll
             for (int r = 0; r < kNL; ++r) {
-                const float4 q = Q::cvt(L[r]);
-                mx = max(max(mx, __float_as_uint(q.x)), max(max(__float_as_uint(q.y), __float_as_uint(q.z)), __float_as_uint(q.w)));
-                if (col_ok & (lrowc + r * kRowcPerPass < nrowc)) dst[r * (kRowcPerPass * kCols)] = q;
+                float4 q[TPI / 4];
+                Q::cvt(L[r], q);
+                const bool ok = col_ok & (lrowc + r * kRowcPerPass < nrowc);
+#pragma unroll
+                for (int h = 0; h < TPI / 4; ++h) {
+                    mx = max(max(mx, __float_as_uint(q[h].x)), max(max(__float_as_uint(q[h].y), __float_as_uint(q[h].z)), __float_as_uint(q[h].w)));
+                    if (ok) dst[r * (kRowcPerPass * (kPitch / 4)) + h] = q[h];
+                }
             }
             // [0,1] test on bit patterns: non-negative floats order like unsigned ints, so v in [0,1] <=> bits <=
             // 0x3f800000; negative values (sign bit) and NaN/Inf compare above.  -0.0 is legal: exact re-test (cold).
             if (check_range && __builtin_expect(mx > 0x3f800000u, 0)) {
 #pragma unroll
-                for (int r = 0; r < kNL; ++r)
-                    if (quad_out_of_unit(Q::cvt(L[r]))) bad |= 2u;
+                for (int r = 0; r < kNL; ++r) {
+                    float4 q[TPI / 4];
+                    Q::cvt(L[r], q);
+#pragma unroll
+                    for (int h = 0; h < TPI / 4; ++h)
+                        if (quad_out_of_unit(q[h])) bad |= 2u;
+                }
             }
         };
 
@@ -361,10 +382,10 @@ static int elem_size(int dtype) { return dtype == 0 ? 4 : 2; }
 
 bool lds_variant_supports(const KParams& p, int dtype) {
     const int es = elem_size(dtype);
-    const int quad_bytes = 4 * es;  // one 4-texel quad
-    if (p.Wt % 4 != 0) return false;
-    if (reinterpret_cast<uintptr_t>(p.rgba) % quad_bytes != 0) return false;
-    if (p.s_row % 4 != 0 || p.s_chan % 4 != 0 || p.s_plane % 4 != 0 || p.s_mpi % 4 != 0) return false;
+    const int tpi = 16 / es;  // texels per 16-byte loader item
+    if (p.Wt % tpi != 0) return false;
+    if (reinterpret_cast<uintptr_t>(p.rgba) % 16 != 0) return false;
+    if (p.s_row % tpi != 0 || p.s_chan % tpi != 0 || p.s_plane % tpi != 0 || p.s_mpi % tpi != 0) return false;
     // the in-plane item offset is kept in 32 bits
     const int64_t span = 3 * p.s_chan + (kMaxRows + 1) * p.s_row + 128;
     if (span >= (int64_t(1) << 31) / es) return false;
