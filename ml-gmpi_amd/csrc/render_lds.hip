@@ -100,7 +100,7 @@ __device__ __forceinline__ bool quad_out_of_unit(const float4& q) {
 }
 
 // TW x TH pixel tile, one pixel per thread: lane = (x = tid % TW, y = tid / TW).
-template <typename TexT, bool AC, bool STRICT, int TW, int MINW>
+template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF>
 __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y,
                                                                const int n_tiles) {
     using Q = Quad<TexT>;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         const int rowc = lrowc + r * kRowcPerPass;
         g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) * static_cast<uint32_t>(sizeof(TexT));
     }
-    uint4 L0[kNL], L1[kNL];  // two staging register sets: loads run two planes ahead of the compositor
+    uint4 L[PF][kNL];  // PF staging register sets: loads run PF planes ahead of the compositor
 
     for (int kc = 0; kc < D; kc += kChunk) {
         const int kn = min(kChunk, D - kc);
@@ -336,18 +336,18 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             }
             blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
         };
-        issue_loads(0, L0);
-        issue_loads(1, L1);
-        for (int t = 0; t < kn; t += 2) {
-            store_box(t, tile0, L0);
-            __syncthreads();  // box t visible; everybody is done reading box t-2 (same buffer) and t-1
-            issue_loads(t + 2, L0);  // two planes ahead, in flight while boxes t and t+1 are composited
-            composite(t, tile0);
-            if (t + 1 < kn) {
-                store_box(t + 1, tile0 + kCapFloats, L1);
-                __syncthreads();
-                issue_loads(t + 3, L1);
-                composite(t + 1, tile0 + kCapFloats);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) issue_loads(u, L[u]);
+        for (int t = 0; t < kn; t += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (t + u < kn) {
+                    float* tile = tile0 + ((t + u) & 1) * kCapFloats;
+                    store_box(t + u, tile, L[u]);
+                    __syncthreads();  // box t+u visible; everybody is done reading box t+u-1 (the other buffer)
+                    issue_loads(t + u + PF, L[u]);  // PF planes ahead, in flight while the boxes in between are composited
+                    composite(t + u, tile);
+                }
             }
         }
     }
@@ -403,36 +403,39 @@ int lds_variant_query(int what) {
     }
 }
 
-template <typename TexT, int TW, int MINW>
+template <typename TexT, int TW, int MINW, int PF>
 static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     constexpr int TH = kNT / TW;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int n_tiles = tiles_x * tiles_y * p.N;
     const dim3 grid(((n_tiles + 7) / 8) * 8), block(kNT);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
-    if (ac && strict) hipLaunchKernelGGL((render_lds_kernel<TexT, true, true, TW, MINW>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (ac) hipLaunchKernelGGL((render_lds_kernel<TexT, true, false, TW, MINW>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (strict) hipLaunchKernelGGL((render_lds_kernel<TexT, false, true, TW, MINW>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else hipLaunchKernelGGL((render_lds_kernel<TexT, false, false, TW, MINW>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    if (ac && strict) hipLaunchKernelGGL((render_lds_kernel<TexT, true, true, TW, MINW, PF>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else if (ac) hipLaunchKernelGGL((render_lds_kernel<TexT, true, false, TW, MINW, PF>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else if (strict) hipLaunchKernelGGL((render_lds_kernel<TexT, false, true, TW, MINW, PF>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else hipLaunchKernelGGL((render_lds_kernel<TexT, false, false, TW, MINW, PF>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
     return hipGetLastError();
 }
 
-template <int MINW>
+template <int MINW, int PF>
 static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) {
     switch (dtype) {
-        case 0: return launch_lds_t<float, kTileW, MINW>(p, stream);
-        case 1: return launch_lds_t<bf16_t, kTileW, MINW>(p, stream);
-        default: return launch_lds_t<f16_t, kTileW, MINW>(p, stream);
+        case 0: return launch_lds_t<float, kTileW, MINW, PF>(p, stream);
+        case 1: return launch_lds_t<bf16_t, kTileW, MINW, PF>(p, stream);
+        default: return launch_lds_t<f16_t, kTileW, MINW, PF>(p, stream);
     }
 }
 
 hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
+    // experiment knobs (environment): GMPI_TUNE_MINW 4|6 = waves/SIMD the register allocator targets,
+    // GMPI_TUNE_PF 2|3 = planes of prefetch, GMPI_TUNE_SKIP = ablation bits (see flags bits 16-18)
+    static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 6; }();
+    static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 2; }();
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
     p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores
-    static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 6; }();  // experiment knob (6 = three workgroups per CU)
-    if (tune == 4) return launch_lds_w<4>(p, dtype, stream);
-    return launch_lds_w<6>(p, dtype, stream);
+    if (tune == 4) return pf == 3 ? launch_lds_w<4, 3>(p, dtype, stream) : launch_lds_w<4, 2>(p, dtype, stream);
+    return pf == 3 ? launch_lds_w<6, 3>(p, dtype, stream) : launch_lds_w<6, 2>(p, dtype, stream);
 }
 
 }  // namespace gmpi
