@@ -152,6 +152,7 @@ using namespace gmpi;
 extern "C" {
 
 int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
+    if (params != nullptr && params->struct_size == sizeof(GmpiRenderParams) && params->N == 0) return GMPI_OK;  // no views
     KParams p;
     const int rc = to_kparams(params, p, true);
     if (rc != GMPI_OK) return rc;
