@@ -135,6 +135,19 @@ int gmpi_rgba_range_check_launch(const void *rgba, int32_t rgba_dtype, int64_t c
 int gmpi_frames_to_uint8_launch(const float *rgb_pm1, const float *depth, int32_t N, int32_t H, int32_t W,
                                 double depth_near, double depth_far, uint8_t *img8, uint8_t *dep8, void *stream);
 
+/*
+ * World-space rays of N pinhole views (gmpi/core/camera.py:182-211 `_generate_rays_torch`, called per view
+ * from mpi_renderer.py:320-335): for view n with camera-to-world matrix c2w[n] (row-major 4x4, fp32) and the
+ * camera-frame unit directions unit_dirs [3, H*W] (camera.py:98-118),
+ *     ray_dir[n,c,p] = fma(R[c][2], d2[p], fma(R[c][1], d1[p], R[c][0] * d0[p]))      R = c2w[n][:3,:3]
+ *     eye_pos[n]     = c2w[n][:3,3]            z_dir[n] = R[:,2]
+ * The FMA order is the one of the reference's CPU `torch.matmul` (3x3 @ 3xN sgemm): it reproduces the rays of
+ * the CPU reference bit for bit (tests/test_host_geometry.py, tests/test_hip_parity.py), which the reference's
+ * own GPU path (rocBLAS) does not.  All pointers are device pointers.
+ */
+int gmpi_generate_rays_launch(const float *c2w, const float *unit_dirs, int32_t N, int32_t H, int32_t W,
+                              float *ray_dir, float *eye_pos, float *z_dir, void *stream);
+
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
  * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height.  Unknown -> -1.      */
 int gmpi_query(int32_t what);

@@ -106,6 +106,26 @@ __global__ __launch_bounds__(256) void frames_to_uint8_kernel(const float* __res
     }
 }
 
+// ---- rays of N views: R @ unit_dirs with the CPU sgemm's FMA order (camera.py:189-211) -----------------------
+__global__ __launch_bounds__(256) void generate_rays_kernel(const float* __restrict__ c2w, const float* __restrict__ dirs,
+                                                            int64_t HW, float* __restrict__ ray, float* __restrict__ eye,
+                                                            float* __restrict__ zdir) {
+    const int n = blockIdx.y;
+    const float* m = c2w + 16 * n;
+    const float r00 = m[0], r01 = m[1], r02 = m[2], r10 = m[4], r11 = m[5], r12 = m[6], r20 = m[8], r21 = m[9], r22 = m[10];
+    if (blockIdx.x == 0 && threadIdx.x < 3) {
+        eye[3 * n + threadIdx.x] = m[4 * threadIdx.x + 3];
+        zdir[3 * n + threadIdx.x] = m[4 * threadIdx.x + 2];
+    }
+    const int64_t p = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float d0 = dirs[p], d1 = dirs[HW + p], d2 = dirs[2 * HW + p];
+    float* o = ray + static_cast<int64_t>(n) * 3 * HW + p;
+    o[0] = __builtin_fmaf(r02, d2, __builtin_fmaf(r01, d1, r00 * d0));
+    o[HW] = __builtin_fmaf(r12, d2, __builtin_fmaf(r11, d1, r10 * d0));
+    o[2 * HW] = __builtin_fmaf(r22, d2, __builtin_fmaf(r21, d1, r20 * d0));
+}
+
 static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs) {
     if (q == nullptr) return GMPI_E_NULL;
     if (q->struct_size != sizeof(GmpiRenderParams)) return GMPI_E_ABI;
@@ -218,6 +238,18 @@ int gmpi_frames_to_uint8_launch(const float* rgb_pm1, const float* depth, int32_
     hipLaunchKernelGGL(frames_to_uint8_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        rgb_pm1, depth, HW, total, static_cast<float>(depth_near), static_cast<float>(depth_far - depth_near), img8,
                        dep8);
+    return hip_rc(hipGetLastError());
+}
+
+int gmpi_generate_rays_launch(const float* c2w, const float* unit_dirs, int32_t N, int32_t H, int32_t W, float* ray_dir,
+                              float* eye_pos, float* z_dir, void* stream) {
+    if (N < 0 || H <= 0 || W <= 0) return GMPI_E_SHAPE;
+    if (N == 0) return GMPI_OK;
+    if (!c2w || !unit_dirs || !ray_dir || !eye_pos || !z_dir) return GMPI_E_NULL;
+    const int64_t HW = static_cast<int64_t>(H) * W;
+    const dim3 grid(static_cast<unsigned>((HW + 255) / 256), static_cast<unsigned>(N));
+    hipLaunchKernelGGL(generate_rays_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), c2w, unit_dirs, HW, ray_dir,
+                       eye_pos, z_dir);
     return hip_rc(hipGetLastError());
 }
 

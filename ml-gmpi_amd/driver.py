@@ -128,7 +128,12 @@ class ViewBatchDriver:
             out = dict(color=rgb[s:s + len(chunk)], depth=dep[s:s + len(chunk)])
             if T is not None:
                 out["T"] = T[s:s + len(chunk)]
-            r.mpi.render_views(mpi_rgbas, dhw, torch.cat(rays), torch.cat(eyes), torch.cat(zdirs),
+            if r._batched_cam is not None and rays is r._batched_cam[0]:
+                ray_t, eye_t, zd_t = r._batched_cam[1:]
+            else:
+                ray_t, eye_t, zd_t = torch.cat(rays), torch.cat(eyes), torch.cat(zdirs)
+            r._batched_cam = None
+            r.mpi.render_views(mpi_rgbas, dhw, ray_t, eye_t, zd_t,
                                views_per_mpi=len(chunk), check_last_plane=True, out_pm1=True,
                                want_transmittance=want_transmittance, status=status, defer_status=True, out=out)
         r.mpi.raise_on_status(status)  # one host sync for the whole path

@@ -58,7 +58,8 @@ class MPIRenderer:
                  use_xyz_ztype="depth", use_normalized_xyz=False, normalized_xyz_range="-11",
                  use_confined_volume=False, device=torch.device("cpu"),
                  # extensions (keyword-only, defaults = reference behaviour)
-                 kernel_variant="auto", strict_order=False, range_check="touched", on_out_of_plane="exit"):
+                 kernel_variant="auto", strict_order=False, range_check="touched", on_out_of_plane="exit",
+                 ray_backend="auto"):
         self.mpi = MPI(align_corners=mpi_align_corners, variant=kernel_variant, strict_order=strict_order,
                        range_check=range_check, on_out_of_plane=on_out_of_plane)
         self.use_confined_volume = use_confined_volume
@@ -79,6 +80,13 @@ class MPIRenderer:
         self.cam_pose_n_truncated_stds = cam_pose_n_truncated_stds
         self.cam_sample_method = cam_sample_method
         self.device = device
+        # "torch": rays by torch.matmul on self.device, per view, exactly as the reference (camera.py:201);
+        # "hip": one gmpi_generate_rays_launch for the whole batch, bit-identical to the reference's CPU rays
+        assert ray_backend in ("auto", "torch", "hip"), ray_backend
+        if ray_backend == "auto":
+            ray_backend = "hip" if torch.device(device).type == "cuda" else "torch"
+        self.ray_backend = ray_backend
+        self._batched_cam = None
         self._dhw_dev = None
         self.compute_mpi_spatial_volume()
         self.use_xyz_ztype = use_xyz_ztype
@@ -203,11 +211,37 @@ class MPIRenderer:
             n_truncated_stds=self.cam_pose_n_truncated_stds, flag_rnd=random_pose,
             sample_method=self.cam_sample_method, given_yaws=given_yaws, given_pitches=given_pitches)
         batch_tf_c2w = (c2w if isinstance(c2w, torch.Tensor) else torch.FloatTensor(c2w)).to(self.device)
+        if self.ray_backend == "hip":
+            ray, eye, zd = self._generate_rays_hip(batch_tf_c2w)
+            rays = [ray[i:i + 1] for i in range(ray.shape[0])]      # views of the batched tensors (no copies)
+            eyes = [eye[i:i + 1] for i in range(ray.shape[0])]
+            zdirs = [zd[i:i + 1] for i in range(ray.shape[0])]
+            self._batched_cam = (rays, ray, eye, zd)                 # lets render() skip the torch.cat of the views
+            return yaws, pitches, batch_tf_c2w, rays, eyes, zdirs
         rays, eyes, zdirs = [], [], []
         for i in range(batch_tf_c2w.shape[0]):
             r, e, z, _ = self.view_info_from_c2w_mat(self.cam, batch_tf_c2w[i, ...], device=self.device)
             rays.append(r), eyes.append(e), zdirs.append(z)
         return yaws, pitches, batch_tf_c2w, rays, eyes, zdirs
+
+    def _generate_rays_hip(self, c2w: torch.Tensor):
+        """(ray_dir [B,3,H,W], eye_pos [B,3], z_dir [B,3]) for c2w [B,4,4] on the device -- one launch
+        (`gmpi_generate_rays_launch`), same bits as the reference's CPU `Camera._generate_rays_torch`."""
+        from . import _lib
+        if not c2w.is_cuda:
+            raise _lib.GmpiError("ray_backend='hip' needs a ROCm device (use ray_backend='torch' on the CPU)")
+        lib = _lib.load_library()
+        c2w = c2w.to(torch.float32).contiguous()
+        B, H, W = c2w.shape[0], self.cam.height, self.cam.width
+        dirs = self.cam.unit_dirs(c2w.device)
+        ray = torch.empty((B, 3, H, W), dtype=torch.float32, device=c2w.device)
+        eye = torch.empty((B, 3), dtype=torch.float32, device=c2w.device)
+        zd = torch.empty((B, 3), dtype=torch.float32, device=c2w.device)
+        with torch.cuda.device(c2w.device):
+            _lib.check(lib.gmpi_generate_rays_launch(c2w.data_ptr(), dirs.data_ptr(), B, H, W, ray.data_ptr(), eye.data_ptr(),
+                                                     zd.data_ptr(), torch.cuda.current_stream(c2w.device).cuda_stream),
+                       "gmpi_generate_rays_launch")
+        return ray, eye, zd
 
     # ---- render -------------------------------------------------------------------------------------------------
     def _dhw_on_device(self):
@@ -251,8 +285,13 @@ class MPIRenderer:
 
         dhw = self._dhw_on_device().expand(n_mpis, -1, -1)
         cat = (lambda t: t if isinstance(t, torch.Tensor) else (t[0] if len(t) == 1 else torch.cat(list(t), 0)))
+        if self._batched_cam is not None and rays is self._batched_cam[0]:
+            ray_t, eye_t, zd_t = self._batched_cam[1:]             # the lists are views of these tensors
+        else:
+            ray_t, eye_t, zd_t = cat(rays), cat(eyes), cat(zdirs)
+        self._batched_cam = None
         res = self.mpi.render_views(
-            batch_mpi_rgbas, dhw, cat(rays), cat(eyes), cat(zdirs), views_per_mpi=views_per_mpi,
+            batch_mpi_rgbas, dhw, ray_t, eye_t, zd_t, views_per_mpi=views_per_mpi,
             check_last_plane=assert_not_out_of_last_plane, out_pm1=True, want_transmittance=want_T,
             c2w_mat=c2w, sphere_c=self.sphere_center, defer_status=defer)
         cam_angles = torch.cat([pitches, yaws], -1).to(self.device)
