@@ -148,6 +148,18 @@ int gmpi_frames_to_uint8_launch(const float *rgb_pm1, const float *depth, int32_
 int gmpi_generate_rays_launch(const float *c2w, const float *unit_dirs, int32_t N, int32_t H, int32_t W,
                               float *ray_dir, float *eye_pos, float *z_dir, void *stream);
 
+/*
+ * Expected depth of the UN-WARPED multiplane image (gmpi/core/light_renderer.py:82-100 `LightRenderer.compute_depth`,
+ * the same cumprod weights as mpi.py:421-423 with the identity warp):
+ *     depth[b,y,x] = sum_k a_k * T_k * plane_ds[k],   T_0 = 1,  T_{k+1} = T_k * ((1 - a_k) + 1e-10)
+ * alpha: [B, D, 1, H, W] view (typically channel 3 of the RGBA volume): element strides for B, D and rows are given,
+ * the innermost stride is 1.  depth_out [B,1,H,W]; transmittance_out [B,1,H,W] or NULL.  Streaming kernel: one read
+ * of the alpha planes.
+ */
+int gmpi_alpha_depth_launch(const void *alpha, int32_t alpha_dtype, int64_t stride_b, int64_t stride_d, int64_t stride_row,
+                            const float *plane_ds, int32_t B, int32_t D, int32_t H, int32_t W, float *depth_out,
+                            float *transmittance_out, void *stream);
+
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
  * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height.  Unknown -> -1.      */
 int gmpi_query(int32_t what);

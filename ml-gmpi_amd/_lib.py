@@ -26,6 +26,7 @@ EXPORTS = (
     "gmpi_rgba_range_check_launch",
     "gmpi_frames_to_uint8_launch",
     "gmpi_generate_rays_launch",
+    "gmpi_alpha_depth_launch",
     "gmpi_query",
     "gmpi_version_string",
 )
@@ -105,6 +106,9 @@ def load_library():
                                                 ctypes.c_double, ctypes.c_double, vp, vp, vp]
     lib.gmpi_generate_rays_launch.restype = ctypes.c_int
     lib.gmpi_generate_rays_launch.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp]
+    lib.gmpi_alpha_depth_launch.restype = ctypes.c_int
+    lib.gmpi_alpha_depth_launch.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp,
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
     lib.gmpi_query.restype = ctypes.c_int
     lib.gmpi_query.argtypes = [ctypes.c_int32]
     lib.gmpi_version_string.restype = ctypes.c_char_p

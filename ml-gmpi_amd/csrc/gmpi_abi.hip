@@ -126,6 +126,31 @@ __global__ __launch_bounds__(256) void generate_rays_kernel(const float* __restr
     o[2 * HW] = __builtin_fmaf(r22, d2, __builtin_fmaf(r21, d1, r20 * d0));
 }
 
+// ---- LightRenderer.compute_depth (light_renderer.py:82-100): composite plane depths with the un-warped alphas ----
+template <typename T>
+__global__ __launch_bounds__(256) void alpha_depth_kernel(const T* __restrict__ alpha, int64_t sb, int64_t sd, int64_t sr,
+                                                          const float* __restrict__ ds, int D, int H, int W,
+                                                          float* __restrict__ depth, float* __restrict__ tout) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const T* a = alpha + b * sb + y * sr + x;
+    float Tr = 1.0f, Z = 0.0f;
+#pragma unroll 4
+    for (int k = 0; k < D; ++k) {
+        const float al = to_f32(a[k * sd]);
+        const float w = al * Tr;           // weights = alpha * cumprod[:-1]
+        const float wd = w * ds[k];
+        Z = Z + wd;                        // torch.sum(weights * plane_ds, dim=1)
+        float om = 1.0f - al;
+        om = om + 1e-10f;
+        Tr = Tr * om;
+    }
+    const int64_t o = (static_cast<int64_t>(b) * H + y) * W + x;
+    depth[o] = Z;
+    if (tout) tout[o] = Tr;
+}
+
 static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs) {
     if (q == nullptr) return GMPI_E_NULL;
     if (q->struct_size != sizeof(GmpiRenderParams)) return GMPI_E_ABI;
@@ -250,6 +275,25 @@ int gmpi_generate_rays_launch(const float* c2w, const float* unit_dirs, int32_t 
     const dim3 grid(static_cast<unsigned>((HW + 255) / 256), static_cast<unsigned>(N));
     hipLaunchKernelGGL(generate_rays_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), c2w, unit_dirs, HW, ray_dir,
                        eye_pos, z_dir);
+    return hip_rc(hipGetLastError());
+}
+
+int gmpi_alpha_depth_launch(const void* alpha, int32_t alpha_dtype, int64_t stride_b, int64_t stride_d, int64_t stride_row,
+                            const float* plane_ds, int32_t B, int32_t D, int32_t H, int32_t W, float* depth_out,
+                            float* transmittance_out, void* stream) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0) return GMPI_E_SHAPE;
+    if (B == 0) return GMPI_OK;
+    if (!alpha || !plane_ds || !depth_out) return GMPI_E_NULL;
+    if (alpha_dtype < GMPI_DTYPE_F32 || alpha_dtype > GMPI_DTYPE_F16) return GMPI_E_DTYPE;
+    if (stride_b < 0 || stride_d <= 0 || stride_row < W) return GMPI_E_STRIDE;
+    const dim3 grid((W + 255) / 256, H, B), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (alpha_dtype == GMPI_DTYPE_F32)
+        hipLaunchKernelGGL(alpha_depth_kernel<float>, grid, block, 0, st, static_cast<const float*>(alpha), stride_b, stride_d, stride_row, plane_ds, D, H, W, depth_out, transmittance_out);
+    else if (alpha_dtype == GMPI_DTYPE_BF16)
+        hipLaunchKernelGGL(alpha_depth_kernel<bf16_t>, grid, block, 0, st, static_cast<const bf16_t*>(alpha), stride_b, stride_d, stride_row, plane_ds, D, H, W, depth_out, transmittance_out);
+    else
+        hipLaunchKernelGGL(alpha_depth_kernel<f16_t>, grid, block, 0, st, static_cast<const f16_t*>(alpha), stride_b, stride_d, stride_row, plane_ds, D, H, W, depth_out, transmittance_out);
     return hip_rc(hipGetLastError());
 }
 

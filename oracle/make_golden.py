@@ -178,7 +178,36 @@ def run_geometry(ns):
     print("wrote geometry", len(out), "arrays")
 
 
+def run_light_depth():
+    """LightRenderer.compute_depth (light_renderer.py:82-100).  The module imports torchvision at import time (not
+    installed here, not on this function's path): a stand-in module is registered first."""
+    import importlib
+    import types
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.transforms = types.SimpleNamespace(GaussianBlur=lambda **k: None)
+        sys.modules["torchvision"] = tv
+    if ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    ref_import._install_stubs()
+    lr = importlib.import_module("gmpi.core.light_renderer")
+    B, D, S = 2, 12, 40
+    rgba = oracle.synth_rgba(77, (B, D, 4, S, S))
+    rgba[0, :, 3] = (rgba[0, :, 3] > 0.7).astype(np.float32)  # exact 0/1 alphas in one batch element
+    alpha = torch.from_numpy(rgba)[:, :, 3:]
+    ds = torch.from_numpy(ref_import.import_reference().mpi_utils.sample_distance(0.95, 1.12, D, "inverse"))
+    depth = lr.LightRenderer.compute_depth(None, alpha, ds.reshape(-1, 1))
+    np.savez(os.path.join(OUT, "light_compute_depth.npz"), meta=json.dumps(dict(seed=77, B=B, D=D, S=S)),
+             plane_ds=ds.numpy(), ref_depth=depth.numpy())
+    print("wrote light_compute_depth", tuple(depth.shape))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "light":
+        os.makedirs(OUT, exist_ok=True)
+        torch.set_num_threads(1)
+        run_light_depth()
+        return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
     ns = ref_import.import_reference()
@@ -186,6 +215,7 @@ def main():
         run_render_case(ns, case)
     run_multiview_case(ns)
     run_geometry(ns)
+    run_light_depth()
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by oracle/make_golden.py from the reference at /root/reference "
                 "(apple/ml-gmpi @ 2024_08_07), CPU fp32, torch %s, numpy %s.\n" % (torch.__version__, np.__version__))

@@ -25,6 +25,7 @@
  *   mpi.py:103-109  min/max of u,v on the last plane (the assert_not_out_of_last_plane check)
  *   mpi.py:70-72    every plane distance >= eye_z of the first view
  *   mpi.py:185-187, mpi_renderer.py:447-449  range checks on alpha / rgba
+ *   light_renderer.py:82-100  LightRenderer.compute_depth (gmpi_oracle_alpha_depth)
  *
  * Arithmetic contract: IEEE-754 binary32, one rounding per written operation, no FMA contraction
  * (build with -ffp-contract=off, no -ffast-math; x86-64 SSE2 float math has no excess precision).
@@ -227,6 +228,31 @@ uint32_t gmpi_oracle_range_check(const float *rgba, size_t count) {
     for (size_t i = 0; i < count; ++i)
         if (!(rgba[i] >= 0.0f && rgba[i] <= 1.0f)) bad = 2u;
     return bad;
+}
+
+/*
+ * light_renderer.py:82-100 LightRenderer.compute_depth: alphas_shifted = [1, 1-a+1e-10]; weights = a * cumprod[:-1];
+ * depth = sum_k weights_k * plane_ds_k   (un-warped MPI).  alpha [B,D,H,W] contiguous.
+ */
+int gmpi_oracle_alpha_depth(const float *alpha, const float *plane_ds, int B, int D, int H, int W, float *depth,
+                            float *transmittance) {
+    const size_t HW = (size_t)H * (size_t)W;
+    for (int b = 0; b < B; ++b)
+        for (size_t p = 0; p < HW; ++p) {
+            float T = 1.0f, Z = 0.0f;
+            for (int k = 0; k < D; ++k) {
+                const float a = alpha[((size_t)b * D + k) * HW + p];
+                const float w = a * T;
+                const float wd = w * plane_ds[k];
+                Z = Z + wd;
+                float om = 1.0f - a;
+                om = om + 1e-10f;
+                T = T * om;
+            }
+            depth[(size_t)b * HW + p] = Z;
+            if (transmittance) transmittance[(size_t)b * HW + p] = T;
+        }
+    return 0;
 }
 
 int gmpi_oracle_num_threads(void) {

@@ -49,6 +49,8 @@ def _lib(threads: bool):
         lib.gmpi_oracle_coords.argtypes = [ip, fp, fp, fp] + [ctypes.c_int] * 8 + [fp, fp]
         lib.gmpi_oracle_range_check.restype = ctypes.c_uint32
         lib.gmpi_oracle_range_check.argtypes = [fp, ctypes.c_size_t]
+        lib.gmpi_oracle_alpha_depth.restype = ctypes.c_int
+        lib.gmpi_oracle_alpha_depth.argtypes = [fp, fp] + [ctypes.c_int] * 4 + [fp, fp]
         lib.gmpi_oracle_num_threads.restype = ctypes.c_int
         _LIBS[name] = lib
     return _LIBS[name]
@@ -112,6 +114,21 @@ def coords(dhw, ray_dir, eye, Ht, Wt, view_to_mpi=None, align_corners=True):
     if rc != 0:
         raise RuntimeError(f"gmpi_oracle_coords failed: {rc}")
     return ix, iy
+
+
+def alpha_depth(mpi_alpha, plane_ds):
+    """LightRenderer.compute_depth restated: mpi_alpha [B,D,1,H,W] -> (depth [B,1,H,W], T [B,1,H,W])."""
+    a = _f32(mpi_alpha)
+    B, D, one, H, W = a.shape
+    assert one == 1
+    ds = _f32(plane_ds).reshape(-1)
+    assert ds.size == D
+    depth = np.empty((B, 1, H, W), np.float32)
+    T = np.empty((B, 1, H, W), np.float32)
+    rc = _lib(False).gmpi_oracle_alpha_depth(_ptr(a), _ptr(ds), B, D, H, W, _ptr(depth), _ptr(T))
+    if rc != 0:
+        raise RuntimeError(rc)
+    return depth, T
 
 
 def range_check(rgba) -> int:
