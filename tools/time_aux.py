@@ -1,0 +1,31 @@
+"""Timing of the auxiliary kernels (run on the GPU box): compute_depth, ray generation, range check, uint8 epilogue."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, ml_gmpi_amd
+from ml_gmpi_amd import _lib
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+dev = torch.device("cuda")
+vol = torch.rand((4, 96, 4, 1024, 1024), device=dev)
+ds = torch.linspace(0.95, 1.12, 96)
+ms = timeit(lambda: ml_gmpi_amd.compute_depth(vol[:, :, 3:], ds))
+b = 4 * 96 * 1024 * 1024 * 4
+print(f"compute_depth 4x96x1024^2 fp32 alpha (strided view of RGBA): {ms:.3f} ms  {b/ms/1e6:.0f} GB/s of alpha bytes ({b/ms/1e6/8000:.1%} of 8 TB/s)")
+r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=96, device=dev)
+r.set_cam(r.cam_fov, 1024, 1024)
+c2w = torch.eye(4, device=dev).repeat(8, 1, 1)
+ms = timeit(lambda: r._generate_rays_hip(c2w))
+print(f"generate_rays 8 views 1024^2: {ms:.3f} ms  ({8*1024*1024*12*2/ms/1e6:.0f} GB/s r+w)")
+lib = _lib.load_library(); st = torch.zeros(4, dtype=torch.int32, device=dev)
+ms = timeit(lambda: lib.gmpi_rgba_range_check_launch(vol.data_ptr(), 0, vol.numel(), st.data_ptr(), torch.cuda.current_stream().cuda_stream))
+print(f"range_check full volume 6.4 GB: {ms:.3f} ms  {vol.numel()*4/ms/1e6:.0f} GB/s ({vol.numel()*4/ms/1e6/8000:.1%} of 8 TB/s)")
+rgb = torch.rand((8, 3, 1024, 1024), device=dev) * 2 - 1; dep = torch.rand((8, 1, 1024, 1024), device=dev) + 0.5
+ms = timeit(lambda: ml_gmpi_amd.frames_to_uint8(rgb, dep, 0.95, 1.12))
+print(f"frames_to_uint8 8 frames 1024^2: {ms:.3f} ms")
