@@ -110,6 +110,17 @@ typedef struct GmpiRenderParams {
 int gmpi_mpi_render_launch(const GmpiRenderParams *params, void *stream);
 
 /*
+ * Gradient of the render w.r.t. the RGBA volume -- what autograd computes when the reference's G-step
+ * back-propagates through MPIRenderer.render (gmpi/train.py:740-779; the sampling grid carries no gradient,
+ * mpi.py:65).  `params` are the forward's parameters (outputs may be NULL); grad_rgb [N,3,H,W] is the gradient
+ * w.r.t. the colour the forward wrote (the OUT_PM1 factor 2 is applied inside when that flag is set); grad_depth
+ * [N,1,H,W] or NULL; grad_rgba [M,D,4,Ht,Wt] fp32 with the given element strides (innermost 1) is ACCUMULATED into
+ * (atomicAdd) -- the caller zero-fills it.
+ */
+int gmpi_mpi_render_backward_launch(const GmpiRenderParams *params, const float *grad_rgb, const float *grad_depth,
+                                    float *grad_rgba, const int64_t *grad_rgba_stride, void *stream);
+
+/*
  * Diagnostics for a tripped GMPI_STATUS_OUT_OF_LAST_PLANE: min_u, max_u, min_v, max_v of the
  * normalised grid on the LAST plane per view (what mpi.py:106-109 print).  uv_minmax: [N,4] float.
  * Uses N, M, D, H, W, flags(ALIGN_CORNERS), view_to_mpi/views_per_mpi, dhw, ray_dir, eye_pos.

@@ -22,6 +22,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS}
 
 EXPORTS = (
     "gmpi_mpi_render_launch",
+    "gmpi_mpi_render_backward_launch",
     "gmpi_last_plane_uv_minmax_launch",
     "gmpi_rgba_range_check_launch",
     "gmpi_frames_to_uint8_launch",
@@ -97,6 +98,9 @@ def load_library():
     vp = ctypes.c_void_p
     lib.gmpi_mpi_render_launch.restype = ctypes.c_int
     lib.gmpi_mpi_render_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp]
+    lib.gmpi_mpi_render_backward_launch.restype = ctypes.c_int
+    lib.gmpi_mpi_render_backward_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp, vp, vp,
+                                                    ctypes.POINTER(ctypes.c_int64), vp]
     lib.gmpi_last_plane_uv_minmax_launch.restype = ctypes.c_int
     lib.gmpi_last_plane_uv_minmax_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp, vp]
     lib.gmpi_rgba_range_check_launch.restype = ctypes.c_int

@@ -8,6 +8,8 @@ namespace gmpi {
 
 hipError_t launch_gather(const KParams& p, int dtype, hipStream_t stream);  // render_gather.hip
 hipError_t launch_lds(const KParams& p, int dtype, hipStream_t stream);     // render_lds.hip
+hipError_t launch_backward(const KParams& p, int dtype, const float* g_rgb, const float* g_depth, float* g_rgba,
+                           const int64_t* gstride, hipStream_t stream);    // render_backward.hip
 bool lds_variant_supports(const KParams& p, int dtype);                     // render_lds.hip
 int lds_variant_query(int what);                                            // render_lds.hip
 
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void alpha_depth_kernel(const T* __restrict__ 
     if (tout) tout[o] = Tr;
 }
 
-static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs) {
+static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, bool need_volume = false) {
     if (q == nullptr) return GMPI_E_NULL;
     if (q->struct_size != sizeof(GmpiRenderParams)) return GMPI_E_ABI;
     if (q->N < 0 || q->M <= 0 || q->D <= 0 || q->Ht <= 0 || q->Wt <= 0 || q->H <= 0 || q->W <= 0) return GMPI_E_SHAPE;
@@ -160,8 +162,9 @@ static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs) 
         if (q->N > static_cast<int64_t>(q->M) * q->views_per_mpi) return GMPI_E_SHAPE;
     }
     if (q->dhw == nullptr || q->ray_dir == nullptr || q->eye_pos == nullptr) return GMPI_E_NULL;
-    if (need_outputs) {
-        if (q->rgba == nullptr || q->z_dir == nullptr || q->rgb_out == nullptr || q->depth_out == nullptr) return GMPI_E_NULL;
+    if (need_outputs && (q->rgb_out == nullptr || q->depth_out == nullptr)) return GMPI_E_NULL;
+    if (need_outputs || need_volume) {
+        if (q->rgba == nullptr || q->z_dir == nullptr) return GMPI_E_NULL;
         if (q->rgba_dtype < GMPI_DTYPE_F32 || q->rgba_dtype > GMPI_DTYPE_F16) return GMPI_E_DTYPE;
         if (q->rgba_stride[4] != 1) return GMPI_E_STRIDE;
         for (int i = 0; i < 4; ++i)
@@ -211,6 +214,20 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         return hip_rc(launch_lds(p, params->rgba_dtype, st));
     }
     return GMPI_E_VARIANT;
+}
+
+int gmpi_mpi_render_backward_launch(const GmpiRenderParams* params, const float* grad_rgb, const float* grad_depth,
+                                    float* grad_rgba, const int64_t* grad_rgba_stride, void* stream) {
+    if (params != nullptr && params->struct_size == sizeof(GmpiRenderParams) && params->N == 0) return GMPI_OK;
+    KParams p;
+    const int rc = to_kparams(params, p, false, true);
+    if (rc != GMPI_OK) return rc;
+    if (grad_rgb == nullptr || grad_rgba == nullptr || grad_rgba_stride == nullptr) return GMPI_E_NULL;
+    if (grad_rgba_stride[4] != 1) return GMPI_E_STRIDE;
+    for (int i = 0; i < 4; ++i)
+        if (grad_rgba_stride[i] <= 0 && !(i == 0 && params->M == 1)) return GMPI_E_STRIDE;
+    return hip_rc(launch_backward(p, params->rgba_dtype, grad_rgb, grad_depth, grad_rgba, grad_rgba_stride,
+                                  static_cast<hipStream_t>(stream)));
 }
 
 int gmpi_last_plane_uv_minmax_launch(const GmpiRenderParams* params, float* uv_minmax, void* stream) {

@@ -98,7 +98,8 @@ class MPI(nn.Module):
                      z_dir: torch.Tensor, views_per_mpi: Union[int, Sequence[int]] = 1,
                      view_to_mpi: Optional[torch.Tensor] = None, check_last_plane: bool = False,
                      out_pm1: bool = False, want_transmittance: bool = False, c2w_mat=None, sphere_c=None,
-                     status: Optional[torch.Tensor] = None, defer_status: bool = False, out: Optional[dict] = None):
+                     status: Optional[torch.Tensor] = None, defer_status: bool = False, out: Optional[dict] = None,
+                     _in_autograd_fn: bool = False):
         """Renders N views in one launch.
 
         rgba [M,D,4,Ht,Wt] (f32/bf16/f16, any outer strides, innermost contiguous), dhw [M,D,3],
@@ -107,9 +108,16 @@ class MPI(nn.Module):
         Returns dict(color, depth[, T], status).  With `defer_status` the status word is not read back
         (no host sync); call `raise_on_status` later.
         """
-        if torch.is_grad_enabled() and (rgba.requires_grad or dhw.requires_grad):
-            raise NotImplementedError("the HIP renderer is forward-only; call it under torch.no_grad() "
-                                      "(backward of the fused op is not implemented)")
+        if torch.is_grad_enabled() and dhw.requires_grad:
+            raise NotImplementedError("no gradient flows to the plane geometry (the reference computes the grid under "
+                                      "torch.no_grad(), mpi.py:65)")
+        if torch.is_grad_enabled() and rgba.requires_grad and not _in_autograd_fn:
+            # G-step of the reference (train.py:740-779): gradient w.r.t. the RGBA volume through the fused backward
+            kwargs = dict(views_per_mpi=views_per_mpi, view_to_mpi=view_to_mpi, check_last_plane=check_last_plane,
+                          out_pm1=out_pm1, want_transmittance=want_transmittance, c2w_mat=c2w_mat, sphere_c=sphere_c,
+                          status=status, defer_status=defer_status, out=out)
+            color, depth, T, st = _RenderFunction.apply(rgba, self, dhw, ray_dir, eye_pos, z_dir, kwargs)
+            return dict(color=color, depth=depth, T=T if want_transmittance else None, status=st)
         if not rgba.is_cuda:
             raise _lib.GmpiError("MPI.forward needs tensors on a ROCm device: this package has no CPU path "
                                  f"(got rgba on {rgba.device})")
@@ -194,6 +202,8 @@ class MPI(nn.Module):
                                                             status.data_ptr(), stream), "gmpi_rgba_range_check_launch")
             _lib.check(lib.gmpi_mpi_render_launch(ctypes.byref(p), stream), "gmpi_mpi_render_launch")
         res = dict(color=color, depth=depth, T=T, status=status)
+        if _in_autograd_fn:  # what the backward needs to rebuild the launch
+            res["_bwd"] = (p, (rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi))
         if not defer_status:
             self.raise_on_status(status, params=p, keep=(rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi),
                                  c2w_mat=c2w_mat, sphere_c=sphere_c)
@@ -243,6 +253,37 @@ class MPI(nn.Module):
                 print(f"AssertionError: {msg}", file=sys.stderr)
                 sys.exit(1)
             raise RuntimeError(msg)
+
+
+class _RenderFunction(torch.autograd.Function):
+    """autograd bridge: forward = gmpi_mpi_render_launch, backward = gmpi_mpi_render_backward_launch (d/d rgba)."""
+
+    @staticmethod
+    def forward(ctx, rgba, mpi, dhw, ray_dir, eye_pos, z_dir, kwargs):
+        res = mpi.render_views(rgba.detach(), dhw, ray_dir, eye_pos, z_dir, _in_autograd_fn=True, **kwargs)
+        ctx.params, ctx.keep = res.pop("_bwd")
+        ctx.rgba_dtype, ctx.rgba_shape = rgba.dtype, tuple(rgba.shape)
+        T = res["T"] if res["T"] is not None else res["depth"].new_empty(0)
+        ctx.mark_non_differentiable(res["status"], T)  # gradient w.r.t. the transmittance output is not provided
+        return res["color"], res["depth"], T, res["status"]
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth, g_T, g_status):
+        lib = _lib.load_library()
+        p = ctx.params
+        rgba = ctx.keep[0]
+        dev = rgba.device
+        grad = torch.zeros(ctx.rgba_shape, dtype=torch.float32, device=dev)
+        if g_color is None:
+            g_color = torch.zeros((p.N, 3, p.H, p.W), dtype=torch.float32, device=dev)
+        g_color = g_color.to(torch.float32).contiguous()
+        g_depth = None if g_depth is None else g_depth.to(torch.float32).contiguous()
+        gstride = (ctypes.c_int64 * 5)(*grad.stride())
+        with torch.cuda.device(dev):
+            _lib.check(lib.gmpi_mpi_render_backward_launch(
+                ctypes.byref(p), g_color.data_ptr(), g_depth.data_ptr() if g_depth is not None else None,
+                grad.data_ptr(), gstride, torch.cuda.current_stream(dev).cuda_stream), "gmpi_mpi_render_backward_launch")
+        return grad.to(ctx.rgba_dtype), None, None, None, None, None, None
 
 
 HipMPI = MPI

@@ -1,0 +1,99 @@
+"""Backward of the fused render (gradient w.r.t. the RGBA volume; reference: autograd through MPI.forward in the
+G-step, gmpi/train.py:740-779).  The HIP backward (fp32, atomics) is compared with torch autograd on a float64
+restatement of the same forward (tests/_torch_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from _torch_ref import torch_render
+from test_hip_edge_cases import _cam, _dhw
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(N, M, D, Ht, Wt, H, W, seed, v2m=None):
+    rgba = oracle.synth_rgba(seed, (M, D, 4, Ht, Wt))
+    ray, eye, zd = _cam(N, H, W, seed=seed + 1, tilt=0.3)
+    dhw = _dhw(M, D)
+    v2m = np.arange(N) % M if v2m is None else np.asarray(v2m)
+    return rgba, dhw, ray, eye, zd, v2m
+
+
+def _ref_grads(rgba, dhw, ray, eye, zd, v2m, gc, gd, ac):
+    t = lambda a: torch.from_numpy(np.asarray(a)).double()
+    vol = t(rgba).requires_grad_(True)
+    color, depth = torch_render(vol, t(dhw), t(ray), t(eye), t(zd), v2m, align_corners=ac)
+    loss = (color * t(gc)).sum() + (depth * t(gd)).sum()
+    loss.backward()
+    return color.detach().numpy(), depth.detach().numpy(), vol.grad.numpy()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=2, M=2, D=6, Ht=24, Wt=28, H=20, W=22, ac=True),
+    dict(N=3, M=1, D=5, Ht=16, Wt=16, H=33, W=17, ac=False),        # several views of one MPI accumulate into one gradient
+    dict(N=2, M=2, D=8, Ht=64, Wt=64, H=64, W=64, ac=True, variant="lds"),
+])
+def test_backward_matches_autograd(cfg):
+    from ml_gmpi_amd import MPI
+    ac = cfg["ac"]
+    rgba, dhw, ray, eye, zd, v2m = _setup(cfg["N"], cfg["M"], cfg["D"], cfg["Ht"], cfg["Wt"], cfg["H"], cfg["W"], seed=41)
+    g = np.random.default_rng(5)
+    gc = g.standard_normal((cfg["N"], 3, cfg["H"], cfg["W"])).astype(np.float32)
+    gd = g.standard_normal((cfg["N"], 1, cfg["H"], cfg["W"])).astype(np.float32)
+    ref_c, ref_d, ref_g = _ref_grads(rgba, dhw, ray, eye, zd, v2m, gc, gd, ac)
+
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    vol = t(rgba).requires_grad_(True)
+    mpi = MPI(align_corners=ac, variant=cfg.get("variant", "auto"), on_out_of_plane="raise")
+    out = mpi.render_views(vol, t(dhw), t(ray), t(eye), t(zd), view_to_mpi=t(v2m.astype(np.int32)), check_last_plane=False)
+    assert out["color"].requires_grad and out["depth"].requires_grad
+    assert np.abs(out["color"].detach().cpu().numpy() - ref_c).max() <= 1e-5
+    loss = (out["color"] * t(gc)).sum() + (out["depth"] * t(gd)).sum()
+    loss.backward()
+    got = vol.grad.cpu().numpy()
+    scale = np.abs(ref_g).max()
+    assert np.abs(got - ref_g).max() <= 2e-5 * scale + 1e-6, (np.abs(got - ref_g).max(), scale)
+    # relative check on the significant entries
+    big = np.abs(ref_g) > 1e-3 * scale
+    assert np.max(np.abs(got[big] - ref_g[big]) / np.abs(ref_g[big])) <= 2e-3
+
+
+def test_backward_through_renderer_render_pm1_and_expand():
+    """MPIRenderer.render under grad: colour in [-1,1] (factor 2), expanded volume (n_view_per_z pattern, train.py:553-558)."""
+    from ml_gmpi_amd import make_renderer
+    dev = torch.device("cuda:0")
+    D, S, K = 4, 32, 2
+    r = make_renderer("FFHQ", n_planes=D, device=dev, on_out_of_plane="raise")
+    base = torch.from_numpy(oracle.synth_rgba(43, (1, D, 4, S, S))).to(dev).requires_grad_(True)
+    vol = base.unsqueeze(0).expand(K, -1, -1, -1, -1, -1).reshape(K, D, 4, S, S)   # materialises, grads sum back into `base`
+    torch.manual_seed(3)
+    rgb, depth, c2w, ang = r.render(vol, S, S)
+    gc = torch.randn_like(rgb)
+    (rgb * gc).sum().backward()
+    assert base.grad is not None and torch.isfinite(base.grad).all() and float(base.grad.abs().max()) > 0
+    # cross-check with autograd on the float64 restatement, same cameras
+    torch.manual_seed(3)
+    cam = r.sample_cam_poses(K, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    vol64 = base.detach().double().cpu().requires_grad_(True)
+    dhw = r.static_mpi_plane_dhws.double().reshape(1, -1, 3)
+    color, _ = torch_render(vol64, dhw, torch.cat(cam[3]).double().cpu(), torch.cat(cam[4]).double().cpu(),
+                            torch.cat(cam[5]).double().cpu(), [0] * K)
+    ((2 * color - 1) * gc.double().cpu()).sum().backward()
+    ref = vol64.grad.numpy()
+    got = base.grad.cpu().numpy()
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+
+
+def test_no_gradient_to_geometry_and_no_grad_mode():
+    from ml_gmpi_amd import MPI
+    rgba, dhw, ray, eye, zd, v2m = _setup(1, 1, 3, 16, 16, 16, 16, seed=47)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mpi = MPI(on_out_of_plane="raise")
+    with pytest.raises(NotImplementedError):
+        mpi.render_views(t(rgba), t(dhw).requires_grad_(True), t(ray), t(eye), t(zd))
+    with torch.no_grad():
+        out = mpi.render_views(t(rgba).requires_grad_(True), t(dhw), t(ray), t(eye), t(zd))
+    assert not out["color"].requires_grad

@@ -277,9 +277,9 @@ def test_mpi_forward_signature_and_renderer_render():
         rgb3, _, c2w3, _ = rt.render(t(fx["rgba"]), 32, 32)
     assert np.array_equal(c2w3.cpu().numpy(), fx["c2w"])
     assert np.abs(rgb3.cpu().numpy() - fx["ref_rgb_pm1"]).max() <= 5e-3
-    with pytest.raises(NotImplementedError):
-        x = t(fx["rgba"]).requires_grad_(True)
-        r.render(x, 32, 32, given_cam_infos=infos)
+    x = t(fx["rgba"]).requires_grad_(True)   # under grad the fused backward is attached (tests/test_hip_backward.py)
+    rgb4 = r.render(x, 32, 32, given_cam_infos=infos)[0]
+    assert rgb4.requires_grad and torch.equal(rgb4.detach(), rgb)
     with pytest.raises(Exception):
         r.mpi.render_views(torch.from_numpy(fx["rgba"]), torch.from_numpy(fx["dhw"]), torch.from_numpy(fx["ray_dir"]),
                            torch.from_numpy(fx["eye"]), torch.from_numpy(fx["zdir"]))  # CPU tensors: no fallback
