@@ -9,7 +9,8 @@
 // order with a per-plane pitch, and every pixel takes its 16 taps with 8 ds_read2_b32 (x0,x1 pairs).
 // Texels outside the texture are stored as zeros, so the consumer needs no masks ("zeros" padding of
 // F.grid_sample).  Two LDS buffers + register staging give a one-barrier-per-plane pipeline: loads
-// of plane k+1 are in flight while plane k is composited.
+// of plane k+1 are in flight while plane k is composited (a second prefetch stage costs registers --
+// spills at 3 workgroups/CU -- and gains nothing: profiles/r01_ablation.txt).
 //
 // Box size.  Tilted cameras shear and stretch the footprint: a 32x16 pixel tile needs 33x17 texels
 // for a frontal view, 37x20 at (yaw 0.3, pitch 0.1), 47x29 at the 2-sigma FFHQ pose (64-wide tiles
@@ -175,46 +176,50 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
 
     for (int kc = 0; kc < D; kc += kChunk) {
         const int kn = min(kChunk, D - kc);
-        __syncthreads();  // previous chunk's table / tiles are no longer read
-        // ---- per-plane geometry: texel box of this tile from its 4 corner pixels ---------------------------
-        bool unfit = false;
-        for (int t = tid; t < kn; t += kNT) {
-            const int k = kc + t;
-            const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
-            const float zdiff = d - ez;
-            float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
-            bool finite = true;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int64_t q = static_cast<int64_t>((c & 2) ? cy1 : cy0) * W + ((c & 1) ? cx1 : cx0);
-                float ix, iy, s, u, v;
-                plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, s, u, v);
-                finite = finite && (fabsf(ix) < 1e6f) && (fabsf(iy) < 1e6f);  // false for NaN too
-                mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
+        // ---- per-plane geometry: texel box of the pixel rows [y_lo, y_hi] of this tile from their 4 corner pixels;
+        //      returns (workgroup-uniform) whether some plane's box exceeds the staging buffer ------------------
+        auto build_table = [&](int y_lo, int y_hi) -> bool {
+            __syncthreads();  // the previous table / staging buffers are no longer read
+            bool unfit = false;
+            for (int t = tid; t < kn; t += kNT) {
+                const int k = kc + t;
+                const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
+                const float zdiff = d - ez;
+                float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
+                bool finite = true;
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t q = static_cast<int64_t>((c & 2) ? y_hi : y_lo) * W + ((c & 1) ? cx1 : cx0);
+                    float ix, iy, s, u, v;
+                    plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, s, u, v);
+                    finite = finite && (fabsf(ix) < 1e6f) && (fabsf(iy) < 1e6f);  // false for NaN too
+                    mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
+                }
+                int4 ri = make_int4(0, 0, -1, 0);
+                if (finite) {
+                    const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
+                    const int by0 = static_cast<int>(floorf(mny - kBoxEps)), by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
+                    ri.x = bx0 & ~(TPI - 1);
+                    ri.y = by0;
+                    ri.z = (bx1 - ri.x) / TPI + 1;
+                    ri.w = by1 - by0 + 1;
+                    if (ri.z > kCols || ri.w > kMaxRows) ri.z = -1;
+                    else if (ri.x >= 0 && by0 >= 0 && ri.x + TPI * ri.z <= Wt && by0 + ri.w <= Ht) ri.w |= kInsideBit;
+                }
+                unfit |= ri.z < 0;
+                const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
+                const int64_t goff = static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(ri.y) * s_row + ri.x;
+                tabI[t] = ri;
+                tabF[t] = make_float4(zdiff, hw, hh, 0.f);
+                tabG[t] = make_int4(__float_as_int(1.0f / hw), __float_as_int(1.0f / hh), static_cast<int>(goff & 0xffffffff),
+                                    static_cast<int>(goff >> 32));
             }
-            int4 ri = make_int4(0, 0, -1, 0);
-            if (finite) {
-                const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
-                const int by0 = static_cast<int>(floorf(mny - kBoxEps)), by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
-                ri.x = bx0 & ~(TPI - 1);
-                ri.y = by0;
-                ri.z = (bx1 - ri.x) / TPI + 1;
-                ri.w = by1 - by0 + 1;
-                if (ri.z > kCols || ri.w > kMaxRows) ri.z = -1;
-                else if (ri.x >= 0 && by0 >= 0 && ri.x + TPI * ri.z <= Wt && by0 + ri.w <= Ht) ri.w |= kInsideBit;
-            }
-            unfit |= ri.z < 0;
-            const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
-            const int64_t goff = static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(ri.y) * s_row + ri.x;
-            tabI[t] = ri;
-            tabF[t] = make_float4(zdiff, hw, hh, 0.f);
-            tabG[t] = make_int4(__float_as_int(1.0f / hw), __float_as_int(1.0f / hh), static_cast<int>(goff & 0xffffffff),
-                                static_cast<int>(goff >> 32));
-        }
-        const bool chunk_unfit = __syncthreads_or(unfit);  // also publishes the table
+            return __syncthreads_or(unfit);  // also publishes the table
+        };
 
-        if (chunk_unfit) {
-            // ---- some box of this chunk exceeds the staging buffer: the whole chunk takes the direct gather
+        // ---- last resort (texture much finer than the image, degenerate rays): direct gather, same arithmetic ----
+        auto gather_chunk = [&](bool mine) {
+            if (!mine) return;
             for (int t = 0; t < kn; ++t) {
                 const float4 rf = tabF[t];
                 float ix, iy, s, u, v;
@@ -224,8 +229,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                                             check_range, bad, smp);
                 blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
             }
-            continue;
-        }
+        };
 
         // ---- register staging of one plane's box: branch-free raw buffer loads --------------------------------
         // One buffer resource per plane (its 4 channel images); items that fall outside the box or outside the
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             }
         };
 
-        auto composite = [&](int t, const float* __restrict__ tile) {
-            if (p.flags & (1u << 17)) return;
+        auto composite = [&](int t, const float* __restrict__ tile, bool mine) {
+            if (!mine || (p.flags & (1u << 17))) return;
             const int4 ri = tabI[t];
             const float4 rf = tabF[t];
             const int4 rg = tabG[t];
@@ -336,19 +340,38 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             }
             blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
         };
-#pragma unroll
-        for (int u = 0; u < PF; ++u) issue_loads(u, L[u]);
-        for (int t = 0; t < kn; t += PF) {
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                if (t + u < kn) {
-                    float* tile = tile0 + ((t + u) & 1) * kCapFloats;
-                    store_box(t + u, tile, L[u]);
-                    __syncthreads();  // box t+u visible; everybody is done reading box t+u-1 (the other buffer)
-                    issue_loads(t + u + PF, L[u]);  // PF planes ahead, in flight while the boxes in between are composited
-                    composite(t + u, tile);
+        auto run_staged = [&](bool mine) {
+    #pragma unroll
+            for (int u = 0; u < PF; ++u) issue_loads(u, L[u]);
+            for (int t = 0; t < kn; t += PF) {
+    #pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    if (t + u < kn) {
+                        float* tile = tile0 + ((t + u) & 1) * kCapFloats;
+                        store_box(t + u, tile, L[u]);
+                        __syncthreads();  // box t+u visible; everybody is done reading box t+u-1 (the other buffer)
+                        issue_loads(t + u + PF, L[u]);  // PF planes ahead, in flight while the boxes in between are composited
+                        composite(t + u, tile, mine);
+                    }
                 }
             }
+        };
+
+        // ---- whole tile if every box fits; else its two 32x8 halves one after the other (tilted cameras shear the
+        //      box: 47x29 texels at the 2-sigma FFHQ pose, 21 rows per half); else the direct gather ------------------
+        // (one loop, one call site per lambda: a second inlined copy of the plane loop costs registers in the first)
+        const int half = (tid / TW) / (TH / 2);  // wave-uniform: waves 0-3 upper half, 4-7 lower half
+#pragma unroll 1
+        for (int h = -1; h < 2; ++h) {             // h = -1: the whole tile; h = 0, 1: its halves
+            const int y_lo = h < 0 ? cy0 : cy0 + h * (TH / 2);
+            if (y_lo > cy1) break;
+            const int y_hi = h < 0 ? cy1 : min(y_lo + TH / 2 - 1, cy1);
+            const bool unfit = build_table(y_lo, y_hi);
+            if (h < 0 && unfit) continue;          // try the halves
+            const bool mine = h < 0 || half == h;
+            if (!unfit) run_staged(mine);
+            else gather_chunk(mine);
+            if (h < 0) break;
         }
     }
 
@@ -428,14 +451,14 @@ static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) 
 
 hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
     // experiment knobs (environment): GMPI_TUNE_MINW 4|6 = waves/SIMD the register allocator targets,
-    // GMPI_TUNE_PF 2|3 = planes of prefetch, GMPI_TUNE_SKIP = ablation bits (see flags bits 16-18)
+    // GMPI_TUNE_PF 1|2 = planes of prefetch, GMPI_TUNE_SKIP = ablation bits (see flags bits 16-18)
     static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 6; }();
-    static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 2; }();
+    static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 1; }();
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
     p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores
-    if (tune == 4) return pf == 3 ? launch_lds_w<4, 3>(p, dtype, stream) : launch_lds_w<4, 2>(p, dtype, stream);
-    return pf == 3 ? launch_lds_w<6, 3>(p, dtype, stream) : launch_lds_w<6, 2>(p, dtype, stream);
+    if (tune == 4) return pf == 2 ? launch_lds_w<4, 2>(p, dtype, stream) : launch_lds_w<4, 1>(p, dtype, stream);
+    return pf == 2 ? launch_lds_w<6, 2>(p, dtype, stream) : launch_lds_w<6, 1>(p, dtype, stream);
 }
 
 }  // namespace gmpi
