@@ -7,7 +7,7 @@ TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline $*"
+ARGS="--steps 40 --warmup 10 --no-cpu-baseline $*"
 timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
 tail -1 $OUT/bench_trace.log | cut -c1-400
 pmc() { # name counters...
