@@ -33,6 +33,7 @@
 #include "gmpi_device.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace gmpi {
 
@@ -163,24 +164,40 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     const int cx0 = txi * TW, cx1 = min(cx0 + TW - 1, W - 1);
     const int cy0 = tyi * TH, cy1 = min(cy0 + TH - 1, H - 1);
 
-    // ---- loader role: thread -> item column `lcol` of (row,channel) lines lrowc + kRowcPerPass*r ----------------
-    const int lcol = tid % kCols, lrowc = tid / kCols;
-    const bool loader = tid < LC::kLoaders;
+    // ---- loader role, re-derived per chunk from the widest / tallest box of the chunk (set_loader_map below):
+    //      thread -> item column `lcol` of the (row,channel) lines lrowc + perpass*r, r < npass <= kNL.  A frontal
+    //      view needs 6 of the 7 (16-bit) / 10 of the 14 (fp32) item columns, so its lines fit in 1 instead of 2
+    //      (16-bit) / 2 instead of 3 (fp32) passes -- the loader's VALU and request count shrink accordingly.
+    int lcol = 0, lrowc = 0, perpass = kRowcPerPass, npass = kNL, dst_base = 0;
+    bool loader = false;
     uint32_t g_off[kNL];  // BYTE offset of item r inside a plane, relative to the box origin (32-bit voffset)
+    auto set_loader_map = [&](int cols, int max_rows) {
+        // (integer division runs on the VALU: readfirstlane tells the compiler the results are wave-uniform, so the
+        //  `r < npass` tests below become scalar branches instead of exec-mask regions with vmcnt(0) at their ends)
+        perpass = __builtin_amdgcn_readfirstlane(kNT / cols);
+        npass = __builtin_amdgcn_readfirstlane((4 * max_rows + perpass - 1) / perpass);  // <= kNL: fewer columns -> more lines per pass
+        lrowc = tid / cols;
+        lcol = tid - lrowc * cols;
+        loader = lrowc < perpass;
+        dst_base = lrowc * (kPitch / 4) + lcol * (TPI / 4);
 #pragma unroll
-    for (int r = 0; r < kNL; ++r) {
-        const int rowc = lrowc + r * kRowcPerPass;
-        g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) * static_cast<uint32_t>(sizeof(TexT));
-    }
+        for (int r = 0; r < kNL; ++r) {
+            const int rowc = lrowc + r * perpass;
+            g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) * static_cast<uint32_t>(sizeof(TexT));
+        }
+    };
     uint4 L[PF][kNL];  // PF staging register sets: loads run PF planes ahead of the compositor
 
     for (int kc = 0; kc < D; kc += kChunk) {
         const int kn = min(kChunk, D - kc);
         // ---- per-plane geometry: texel box of the pixel rows [y_lo, y_hi] of this tile from their 4 corner pixels;
         //      returns (workgroup-uniform) whether some plane's box exceeds the staging buffer ------------------
+        //      and the largest item count per row / row count of the chunk (for the loader map) -----------------
+        int max_nq = kCols, max_rows = kMaxRows;
         auto build_table = [&](int y_lo, int y_hi) -> bool {
             __syncthreads();  // the previous table / staging buffers are no longer read
-            bool unfit = false;
+            uint32_t nq_bits = 0, row_bits = 0;  // one-hot: the workgroup OR's highest bit is the maximum
+            // (__ockl_wgred_or_i32 = barrier + bitwise OR over the workgroup; __syncthreads_or would reduce !!x)
             for (int t = tid; t < kn; t += kNT) {
                 const int k = kc + t;
                 const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
@@ -206,7 +223,8 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                     if (ri.z > kCols || ri.w > kMaxRows) ri.z = -1;
                     else if (ri.x >= 0 && by0 >= 0 && ri.x + TPI * ri.z <= Wt && by0 + ri.w <= Ht) ri.w |= kInsideBit;
                 }
-                unfit |= ri.z < 0;
+                nq_bits |= ri.z < 0 ? 0x80000000u : 1u << ri.z;
+                row_bits |= 1u << (ri.w & 31);
                 const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
                 const int64_t goff = static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(ri.y) * s_row + ri.x;
                 tabI[t] = ri;
@@ -214,7 +232,11 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 tabG[t] = make_int4(__float_as_int(1.0f / hw), __float_as_int(1.0f / hh), static_cast<int>(goff & 0xffffffff),
                                     static_cast<int>(goff >> 32));
             }
-            return __syncthreads_or(unfit);  // also publishes the table
+            const uint32_t a = __builtin_amdgcn_readfirstlane(__ockl_wgred_or_i32(static_cast<int>(nq_bits)));  // also publishes the table
+            const uint32_t b = __builtin_amdgcn_readfirstlane(__ockl_wgred_or_i32(static_cast<int>(row_bits)));
+            max_nq = 31 - __builtin_clz((a & 0x7fffffffu) | 1u);
+            max_rows = 31 - __builtin_clz(b | 1u);
+            return (a >> 31) != 0;
         };
 
         // ---- last resort (texture much finer than the image, degenerate rays): direct gather, same arithmetic ----
@@ -237,7 +259,8 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
         const uint32_t plane_bytes = static_cast<uint32_t>((3 * s_chan + static_cast<int64_t>(Ht - 1) * s_row + Wt) * sizeof(TexT));
         // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
-        auto issue_loads = [&](int t, uint4 (&L)[kNL]) {
+        auto issue_loads = [&](auto np, int t, uint4 (&L)[kNL]) {
+            constexpr int NP = decltype(np)::value;  // passes of this chunk's loader map (compile-time: see run_staged)
             if (t >= kn || (p.flags & (1u << 16))) return;
             const int4 ri = tabI[t];
             const int qx0 = __builtin_amdgcn_readfirstlane(ri.x), by0 = __builtin_amdgcn_readfirstlane(ri.y);
@@ -255,47 +278,49 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             if (nrw & kInsideBit) {  // box inside the texture (wave-uniform): no bounds tests
                 const bool col_ok = loader & (lcol < nq);
 #pragma unroll
-                for (int r = 0; r < kNL; ++r) {
-                    const bool ok = col_ok & (lrowc + r * kRowcPerPass < nrowc);
+                for (int r = 0; r < NP; ++r) {
+                    const bool ok = col_ok & (lrowc + r * perpass < nrowc);
                     const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;  // >= num_records (< 2^31); off+15 cannot wrap
                     L[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
                 }
             } else {
                 const bool col_ok = loader & (lcol < nq) & (static_cast<unsigned>(qx0 + TPI * lcol) < static_cast<unsigned>(Wt));
 #pragma unroll
-                for (int r = 0; r < kNL; ++r) {
-                    const int rowc = lrowc + r * kRowcPerPass;
+                for (int r = 0; r < NP; ++r) {
+                    const int rowc = lrowc + r * perpass;
                     const bool ok = col_ok & (rowc < nrowc) & (static_cast<unsigned>(by0 + (rowc >> 2)) < static_cast<unsigned>(Ht));
                     const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;
                     L[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
                 }
             }
         };
-        auto store_box = [&](int t, float* tile, uint4 (&L)[kNL]) {
+        auto store_box = [&](auto np, int t, float* tile, uint4 (&L)[kNL]) {
+            constexpr int NP = decltype(np)::value;
             if (p.flags & (1u << 18)) return;
             const int4 ri = tabI[t];
             const int nq = __builtin_amdgcn_readfirstlane(ri.z);
             const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & ~kInsideBit) * 4;
-            // LDS slot of item r: line (lrowc + kRowcPerPass*r), floats [TPI*lcol, TPI*lcol + TPI)
-            float4* dst = reinterpret_cast<float4*>(tile) + (lrowc * (kPitch / 4) + lcol * (TPI / 4));
+            // LDS slot of item r: line (lrowc + perpass*r), floats [TPI*lcol, TPI*lcol + TPI)
+            float4* dst = reinterpret_cast<float4*>(tile) + dst_base;
+            const int pass_stride = perpass * (kPitch / 4);
             const bool col_ok = loader & (lcol < nq);
             uint32_t mx = 0;  // max of the fp32 bit patterns staged by this lane (lanes outside the box hold zeros)
 #pragma unroll
-            for (int r = 0; r < kNL; ++r) {
+            for (int r = 0; r < NP; ++r) {
                 float4 q[TPI / 4];
                 Q::cvt(L[r], q);
-                const bool ok = col_ok & (lrowc + r * kRowcPerPass < nrowc);
+                const bool ok = col_ok & (lrowc + r * perpass < nrowc);
 #pragma unroll
                 for (int h = 0; h < TPI / 4; ++h) {
                     mx = max(max(mx, __float_as_uint(q[h].x)), max(max(__float_as_uint(q[h].y), __float_as_uint(q[h].z)), __float_as_uint(q[h].w)));
-                    if (ok) dst[r * (kRowcPerPass * (kPitch / 4)) + h] = q[h];
+                    if (ok) dst[r * pass_stride + h] = q[h];
                 }
             }
             // [0,1] test on bit patterns: non-negative floats order like unsigned ints, so v in [0,1] <=> bits <=
             // 0x3f800000; negative values (sign bit) and NaN/Inf compare above.  -0.0 is legal: exact re-test (cold).
             if (check_range && __builtin_expect(mx > 0x3f800000u, 0)) {
 #pragma unroll
-                for (int r = 0; r < kNL; ++r) {
+                for (int r = 0; r < NP; ++r) {
                     float4 q[TPI / 4];
                     Q::cvt(L[r], q);
 #pragma unroll
@@ -340,17 +365,17 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             }
             blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
         };
-        auto run_staged = [&](bool mine) {
+        auto run_staged = [&](auto np, bool mine) {
     #pragma unroll
-            for (int u = 0; u < PF; ++u) issue_loads(u, L[u]);
+            for (int u = 0; u < PF; ++u) issue_loads(np, u, L[u]);
             for (int t = 0; t < kn; t += PF) {
     #pragma unroll
                 for (int u = 0; u < PF; ++u) {
                     if (t + u < kn) {
                         float* tile = tile0 + ((t + u) & 1) * kCapFloats;
-                        store_box(t + u, tile, L[u]);
+                        store_box(np, t + u, tile, L[u]);
                         __syncthreads();  // box t+u visible; everybody is done reading box t+u-1 (the other buffer)
-                        issue_loads(t + u + PF, L[u]);  // PF planes ahead, in flight while the boxes in between are composited
+                        issue_loads(np, t + u + PF, L[u]);  // PF planes ahead, in flight while the boxes in between are composited
                         composite(t + u, tile, mine);
                     }
                 }
@@ -369,7 +394,14 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             const bool unfit = build_table(y_lo, y_hi);
             if (h < 0 && unfit) continue;          // try the halves
             const bool mine = h < 0 || half == h;
-            if (!unfit) run_staged(mine);
+            if (!unfit) set_loader_map((p.flags & (1u << 19)) ? kCols : max_nq, (p.flags & (1u << 19)) ? kMaxRows : max_rows);
+            // the pass count is a compile-time constant of the plane loop (a run-time trip count makes hipcc wait for
+            // the prefetch, vmcnt(0), before compositing): one instance per count, selected per chunk
+            if (!unfit) {
+                if (kNL >= 3 && npass >= 3) run_staged(std::integral_constant<int, (kNL >= 3 ? 3 : 1)>{}, mine);
+                else if (kNL >= 2 && npass == 2) run_staged(std::integral_constant<int, (kNL >= 2 ? 2 : 1)>{}, mine);
+                else run_staged(std::integral_constant<int, 1>{}, mine);
+            }
             else gather_chunk(mine);
             if (h < 0) break;
         }
@@ -451,12 +483,12 @@ static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) 
 
 hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
     // experiment knobs (environment): GMPI_TUNE_MINW 4|6 = waves/SIMD the register allocator targets,
-    // GMPI_TUNE_PF 1|2 = planes of prefetch, GMPI_TUNE_SKIP = ablation bits (see flags bits 16-18)
+    // GMPI_TUNE_PF 1|2 = planes of prefetch, GMPI_TUNE_SKIP = ablation bits (see flags bits 16-19)
     static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 6; }();
     static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 1; }();
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
-    p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores
+    p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores, 8 = static loader map
     if (tune == 4) return pf == 2 ? launch_lds_w<4, 2>(p, dtype, stream) : launch_lds_w<4, 1>(p, dtype, stream);
     return pf == 2 ? launch_lds_w<6, 2>(p, dtype, stream) : launch_lds_w<6, 1>(p, dtype, stream);
 }
