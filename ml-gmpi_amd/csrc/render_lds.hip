@@ -40,41 +40,49 @@ namespace gmpi {
 constexpr int kNT = 512;              // threads per workgroup (8 wavefronts)
 constexpr int kChunk = 96;            // planes per geometry-table refill
 constexpr int kRecBytes = 48;         // per-plane record: three 16-byte LDS broadcasts
-constexpr int kPitch = 56;            // floats per (row,channel) line in LDS; the texel-row stride 4*56 floats is a multiple
-                                      // of the 32 LDS banks, so taps of lanes on neighbouring texel rows do not conflict
-constexpr int kMaxLines = 108;        // (row,channel) lines per staging buffer = 27 box rows
-constexpr int kMaxRows = kMaxLines / 4;
-constexpr int kCapFloats = kMaxLines * kPitch;  // 6048 floats (24.2 KB) per staging buffer, two buffers
-constexpr int kInsideBit = 1 << 30;
+constexpr int kMaxStagedItems = 4;    // 16-byte items (4 VGPRs each) a thread may hold in flight: 80 VGPRs at 6 waves/SIMD
 constexpr float kBoxEps = 1.0f / 64;  // slack on the corner-derived box (fp32 error of ix is < 1e-3 texel)
-constexpr int kLdsBytes = kChunk * kRecBytes + 2 * kCapFloats * 4;  // 52,992 B -> 3 workgroups per CU
+
+// Staging-buffer geometry per tile shape.  kPitch = floats per (row,channel) line in LDS (a multiple of 8: the texel-row
+// stride 4*kPitch floats is then a multiple of the 32 LDS banks, so taps of lanes on neighbouring texel rows do not
+// conflict); kMaxLines = (row,channel) lines per staging buffer.  Two buffers + the table must stay <= 53 KB for
+// 3 workgroups per CU.
+//   32x16 pixels: boxes 33x17 texels frontal ... 47x29 at the 2-sigma FFHQ pose      -> 56 floats x 27 rows
+//   64x8  pixels: boxes 65x9 frontal (longer lines: fewer partially used 128-byte
+//                 cache lines per texel), taller and wider when the camera tilts       -> 96 floats x 14 rows
+template <int TW> struct TileCfg;
+template <> struct TileCfg<32> { static constexpr int kPitch = 56, kMaxLines = 108; };
+template <> struct TileCfg<64> { static constexpr int kPitch = 96, kMaxLines = 56; };
+template <int TW> constexpr int lds_bytes() { return kChunk * kRecBytes + 2 * TileCfg<TW>::kMaxLines * TileCfg<TW>::kPitch * 4; }
+static_assert(lds_bytes<32>() <= 53 * 1024 && lds_bytes<64>() <= 53 * 1024, "3 workgroups per CU");
 
 // Loader geometry: one item = 16 bytes of storage = TPI texels; a box line holds kPitch/TPI items.
-template <int TPI> struct LoaderCfg {
-    static constexpr int kCols = kPitch / TPI;                 // 14 (fp32) / 7 (16-bit) lanes per line
+template <int TPI, int TW> struct LoaderCfg {
+    static constexpr int kCols = TileCfg<TW>::kPitch / TPI;        // 32-wide tiles: 14 (fp32) / 7 (16-bit) items per line
     static constexpr int kLinesPerPass = kNT / kCols;            // 36 / 73 lines per pass
-    static constexpr int kNL = (kMaxLines + kLinesPerPass - 1) / kLinesPerPass;  // 3 / 2 passes
-    static constexpr int kLoaders = kLinesPerPass * kCols;       // 504 / 511 loader threads
+    static constexpr int kNL = (TileCfg<TW>::kMaxLines + kLinesPerPass - 1) / kLinesPerPass;  // 3 / 2 passes at most
 };
 
 // Per-plane record of the current chunk (LDS):
 //   tabI: qx0, by0 (box origin in texels, qx0 multiple of the item width), nq (items per row; < 0: box does not fit),
-//         nrows (| kInsideBit when the box lies completely inside the texture)
+//         nrows; both carry, in bits 8-15 / 16-23, the sub-range [lo, hi) of items / rows that lies inside the texture
 //   tabF: zdiff = d - eye_z, hw = w/2, hh = h/2
 //   tabG: RN(1/hw), RN(1/hh), 64-bit element offset of the box origin inside the MPI volume
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // storage -> fp32: one loader item is ALWAYS 16 bytes of storage (4 fp32 texels or 8 half-precision texels:
 // the load path is request-bound, so 16-bit volumes move twice the texels per request) -----------------------
 template <typename TexT> struct Quad;
 template <> struct Quad<float> {
     static constexpr int kTexels = 4;
-    static __device__ __forceinline__ void cvt(const uint4& v, float4 (&o)[1]) {
+    static __device__ __forceinline__ void cvt(const u32x4& v, float4 (&o)[1]) {
         o[0] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
 };
 template <> struct Quad<bf16_t> {
     static constexpr int kTexels = 8;
-    static __device__ __forceinline__ void cvt(const uint4& v, float4 (&o)[2]) {
+    static __device__ __forceinline__ void cvt(const u32x4& v, float4 (&o)[2]) {
         o[0] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
                            __uint_as_float(v.y & 0xffff0000u));
         o[1] = make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u), __uint_as_float(v.w << 16),
@@ -83,9 +91,10 @@ template <> struct Quad<bf16_t> {
 };
 template <> struct Quad<f16_t> {
     static constexpr int kTexels = 8;
-    static __device__ __forceinline__ void cvt(const uint4& v, float4 (&o)[2]) {
+    static __device__ __forceinline__ void cvt(const u32x4& v, float4 (&o)[2]) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 a = __builtin_bit_cast(h2, v.x), b = __builtin_bit_cast(h2, v.y), c = __builtin_bit_cast(h2, v.z), d = __builtin_bit_cast(h2, v.w);
+        const uint32_t vx = v.x, vy = v.y, vz = v.z, vw = v.w;  // (bit_cast of an ext-vector element lvalue reads element 0)
+        const h2 a = __builtin_bit_cast(h2, vx), b = __builtin_bit_cast(h2, vy), c = __builtin_bit_cast(h2, vz), d = __builtin_bit_cast(h2, vw);
         o[0] = make_float4(static_cast<float>(a.x), static_cast<float>(a.y), static_cast<float>(b.x), static_cast<float>(b.y));
         o[1] = make_float4(static_cast<float>(c.x), static_cast<float>(c.y), static_cast<float>(d.x), static_cast<float>(d.y));
     }
@@ -106,7 +115,9 @@ template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF>
 __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y,
                                                                const int n_tiles) {
     using Q = Quad<TexT>;
-    using LC = LoaderCfg<Q::kTexels>;
+    using LC = LoaderCfg<Q::kTexels, TW>;
+    constexpr int kPitch = TileCfg<TW>::kPitch, kMaxLines = TileCfg<TW>::kMaxLines, kMaxRows = kMaxLines / 4;
+    constexpr int kCapFloats = kMaxLines * kPitch, kLdsBytes = lds_bytes<TW>();
     constexpr int TPI = Q::kTexels, kCols = LC::kCols, kRowcPerPass = LC::kLinesPerPass, kNL = LC::kNL;
     constexpr int TH = kNT / TW;
 
@@ -186,7 +197,6 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) * static_cast<uint32_t>(sizeof(TexT));
         }
     };
-    uint4 L[PF][kNL];  // PF staging register sets: loads run PF planes ahead of the compositor
 
     for (int kc = 0; kc < D; kc += kChunk) {
         const int kn = min(kChunk, D - kc);
@@ -220,10 +230,16 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                     ri.y = by0;
                     ri.z = (bx1 - ri.x) / TPI + 1;
                     ri.w = by1 - by0 + 1;
-                    if (ri.z > kCols || ri.w > kMaxRows) ri.z = -1;
-                    else if (ri.x >= 0 && by0 >= 0 && ri.x + TPI * ri.z <= Wt && by0 + ri.w <= Ht) ri.w |= kInsideBit;
+                    if (ri.z > kCols || ri.w > kMaxRows) {
+                        ri.z = -1;
+                    } else {  // (qx0 and Wt are multiples of the item width)
+                        const int clo = min(max(-ri.x / TPI, 0), ri.z), chi = min(max((Wt - ri.x) / TPI, 0), ri.z);
+                        const int rlo = min(max(-by0, 0), ri.w), rhi = min(max(Ht - by0, 0), ri.w);
+                        ri.z |= clo << 8 | chi << 16;
+                        ri.w |= rlo << 8 | rhi << 16;
+                    }
                 }
-                nq_bits |= ri.z < 0 ? 0x80000000u : 1u << ri.z;
+                nq_bits |= ri.z < 0 ? 0x80000000u : 1u << (ri.z & 31);
                 row_bits |= 1u << (ri.w & 31);
                 const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
                 const int64_t goff = static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(ri.y) * s_row + ri.x;
@@ -259,12 +275,16 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
         const uint32_t plane_bytes = static_cast<uint32_t>((3 * s_chan + static_cast<int64_t>(Ht - 1) * s_row + Wt) * sizeof(TexT));
         // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
-        auto issue_loads = [&](auto np, int t, uint4 (&L)[kNL]) {
+        auto issue_loads = [&](auto np, int t, u32x4 (&L)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;  // passes of this chunk's loader map (compile-time: see run_staged)
-            if (t >= kn || (p.flags & (1u << 16))) return;
+            // Issued UNCONDITIONALLY, also for planes past the end of the chunk (all offsets out of range then: no
+            // memory access): hipcc's waitcnt insertion only lets a load stay in flight across the next plane's
+            // staged store ("vmcnt(NP)" instead of "vmcnt(0)") if every path issues the same number of loads.
+            const bool live = (t < kn) & !(p.flags & (1u << 16));
+            t = min(t, kn - 1);
             const int4 ri = tabI[t];
             const int qx0 = __builtin_amdgcn_readfirstlane(ri.x), by0 = __builtin_amdgcn_readfirstlane(ri.y);
-            const int nq = __builtin_amdgcn_readfirstlane(ri.z), nrw = __builtin_amdgcn_readfirstlane(ri.w);
+            const int cz = __builtin_amdgcn_readfirstlane(ri.z), rw = __builtin_amdgcn_readfirstlane(ri.w);
             // the descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a waterfall loop
             // (cdna_hip_programming.md T20): pass its inputs through readfirstlane
             const uint64_t pa = reinterpret_cast<uint64_t>(vol + static_cast<int64_t>(kc + t) * s_plane);
@@ -274,36 +294,28 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 reinterpret_cast<void*>(pu), 0, __builtin_amdgcn_readfirstlane(static_cast<int>(plane_bytes)), 0x00020000);
             const uint32_t origin = static_cast<uint32_t>(by0 * static_cast<int>(s_row) + qx0) * static_cast<uint32_t>(sizeof(TexT));
-            const int nrowc = (nrw & ~kInsideBit) * 4;
-            if (nrw & kInsideBit) {  // box inside the texture (wave-uniform): no bounds tests
-                const bool col_ok = loader & (lcol < nq);
+            // item columns [clo, chi) and lines [4 rlo, 4 rhi) of the box lie inside the texture (one unsigned compare
+            // each); everything else reads as zero ("zeros" padding) without touching memory
+            const int clo = (cz >> 8) & 0xff, ncol = ((cz >> 16) & 0xff) - clo;
+            const int llo = 4 * ((rw >> 8) & 0xff), nline = 4 * ((rw >> 16) & 0xff) - llo;
+            const bool col_ok = loader & live & (static_cast<unsigned>(lcol - clo) < static_cast<unsigned>(ncol));
 #pragma unroll
-                for (int r = 0; r < NP; ++r) {
-                    const bool ok = col_ok & (lrowc + r * perpass < nrowc);
-                    const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;  // >= num_records (< 2^31); off+15 cannot wrap
-                    L[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-                }
-            } else {
-                const bool col_ok = loader & (lcol < nq) & (static_cast<unsigned>(qx0 + TPI * lcol) < static_cast<unsigned>(Wt));
-#pragma unroll
-                for (int r = 0; r < NP; ++r) {
-                    const int rowc = lrowc + r * perpass;
-                    const bool ok = col_ok & (rowc < nrowc) & (static_cast<unsigned>(by0 + (rowc >> 2)) < static_cast<unsigned>(Ht));
-                    const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;
-                    L[r] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-                }
+            for (int r = 0; r < NP; ++r) {
+                const bool ok = col_ok & (static_cast<unsigned>(lrowc + (r * perpass - llo)) < static_cast<unsigned>(nline));
+                const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;  // >= num_records (< 2^31); off+15 cannot wrap
+                L[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
             }
         };
-        auto store_box = [&](auto np, int t, float* tile, uint4 (&L)[kNL]) {
+        auto store_box = [&](auto np, int t, float* tile, u32x4 (&L)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;
-            if (p.flags & (1u << 18)) return;
-            const int4 ri = tabI[t];
-            const int nq = __builtin_amdgcn_readfirstlane(ri.z);
-            const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & ~kInsideBit) * 4;
+            const bool live = (t < kn) & !(p.flags & (1u << 18));
+            const int4 ri = tabI[min(t, kn - 1)];
+            const int nq = __builtin_amdgcn_readfirstlane(ri.z) & 0xff;
+            const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & 0xff) * 4;
             // LDS slot of item r: line (lrowc + perpass*r), floats [TPI*lcol, TPI*lcol + TPI)
             float4* dst = reinterpret_cast<float4*>(tile) + dst_base;
             const int pass_stride = perpass * (kPitch / 4);
-            const bool col_ok = loader & (lcol < nq);
+            const bool col_ok = loader & (lcol < nq) & live;
             uint32_t mx = 0;  // max of the fp32 bit patterns staged by this lane (lanes outside the box hold zeros)
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         };
 
         auto composite = [&](int t, const float* __restrict__ tile, bool mine) {
-            if (!mine || (p.flags & (1u << 17))) return;
+            if (!mine | ((p.flags & (1u << 17)) != 0)) return;
             const int4 ri = tabI[t];
             const float4 rf = tabF[t];
             const int4 rg = tabG[t];
@@ -354,30 +366,42 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             const int lx = static_cast<int>(floorf(ix)) - ri.x, ly = static_cast<int>(floorf(iy)) - ri.y;
             // unsigned + clamped: keeps wild coordinates (NaN rays) inside the buffer and proves the base non-negative,
             // so the 8 tap-pair reads become ds_read2_b32 with immediate offsets
-            const uint32_t idx = min(static_cast<uint32_t>(ly * (4 * kPitch) + lx), static_cast<uint32_t>(kCapFloats - 7 * kPitch - 2));
-            const float* __restrict__ t0 = tile + idx;
+            const uint32_t idx = min(static_cast<uint32_t>(__mul24(ly, 4 * kPitch) + lx), static_cast<uint32_t>(kCapFloats - 7 * kPitch - 2));
+            // LDS byte addresses of the two texel rows, made opaque to the optimiser: it would otherwise fold the
+            // buffer's constant offset into every tap address and pay one v_add per ds_read2_b32 (the instruction's
+            // offset fields are 8 bits of dwords: channel strides 0/56/112/168 fit, the staging area's base does not)
+            typedef const float __attribute__((address_space(3))) lds_cfloat;
+            uint32_t tile_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_cfloat*)tile));
+            asm volatile("" : "+s"(tile_addr));
+            uint32_t a_top = tile_addr + 4u * idx, a_bot = a_top + 16u * kPitch;
+            asm volatile("" : "+v"(a_top), "+v"(a_bot));
+            lds_cfloat* __restrict__ top = reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(a_top));
+            lds_cfloat* __restrict__ bot = reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(a_bot));
             float smp[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float t_nw = t0[c * kPitch], t_ne = t0[c * kPitch + 1];
-                const float t_sw = t0[(4 + c) * kPitch], t_se = t0[(4 + c) * kPitch + 1];
+                const float t_nw = top[c * kPitch], t_ne = top[c * kPitch + 1];
+                const float t_sw = bot[c * kPitch], t_se = bot[c * kPitch + 1];
                 smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
             }
             blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
         };
         auto run_staged = [&](auto np, bool mine) {
+            constexpr int NP = decltype(np)::value;
+            constexpr int PFX = NP * PF <= kMaxStagedItems ? PF : (NP * 2 <= kMaxStagedItems ? 2 : 1);  // planes in flight
+            u32x4 L[PFX][NP];  // staging registers: the loads run PFX planes ahead of the compositor
     #pragma unroll
-            for (int u = 0; u < PF; ++u) issue_loads(np, u, L[u]);
-            for (int t = 0; t < kn; t += PF) {
+            for (int u = 0; u < PFX; ++u) issue_loads(np, u, L[u]);
+            // every stage runs for every t (a chunk is padded to a multiple of PFX planes: the padding planes load
+            // and stage nothing and are not composited), so the memory operations are the same on every path
+            for (int t = 0; t < kn; t += PFX) {
     #pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    if (t + u < kn) {
-                        float* tile = tile0 + ((t + u) & 1) * kCapFloats;
-                        store_box(np, t + u, tile, L[u]);
-                        __syncthreads();  // box t+u visible; everybody is done reading box t+u-1 (the other buffer)
-                        issue_loads(np, t + u + PF, L[u]);  // PF planes ahead, in flight while the boxes in between are composited
-                        composite(t + u, tile, mine);
-                    }
+                for (int u = 0; u < PFX; ++u) {
+                    float* tile = tile0 + ((t + u) & 1) * kCapFloats;
+                    store_box(np, t + u, tile, L[u]);
+                    __syncthreads();  // box t+u visible; everybody is done reading box t+u-1 (the other buffer)
+                    issue_loads(np, t + u + PFX, L[u]);  // in flight while the PFX planes before it are composited
+                    composite(t + u, tile, mine & (t + u < kn));
                 }
             }
         };
@@ -442,7 +466,7 @@ bool lds_variant_supports(const KParams& p, int dtype) {
     if (reinterpret_cast<uintptr_t>(p.rgba) % 16 != 0) return false;
     if (p.s_row % tpi != 0 || p.s_chan % tpi != 0 || p.s_plane % tpi != 0 || p.s_mpi % tpi != 0) return false;
     // the in-plane item offset is kept in 32 bits
-    const int64_t span = 3 * p.s_chan + (kMaxRows + 1) * p.s_row + 128;
+    const int64_t span = 3 * p.s_chan + (TileCfg<32>::kMaxLines / 4 + 1) * p.s_row + 128;
     if (span >= (int64_t(1) << 31) / es) return false;
     return true;
 }
@@ -451,7 +475,7 @@ constexpr int kTileW = 32;
 
 int lds_variant_query(int what) {
     switch (what) {
-        case 3: return kLdsBytes;
+        case 3: return lds_bytes<kTileW>();
         case 4: return kTileW;
         case 5: return kNT / kTileW;
         default: return -1;
@@ -472,25 +496,29 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int MINW, int PF>
+template <int TW, int MINW, int PF>
 static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) {
     switch (dtype) {
-        case 0: return launch_lds_t<float, kTileW, MINW, PF>(p, stream);
-        case 1: return launch_lds_t<bf16_t, kTileW, MINW, PF>(p, stream);
-        default: return launch_lds_t<f16_t, kTileW, MINW, PF>(p, stream);
+        case 0: return launch_lds_t<float, TW, MINW, PF>(p, stream);
+        case 1: return launch_lds_t<bf16_t, TW, MINW, PF>(p, stream);
+        default: return launch_lds_t<f16_t, TW, MINW, PF>(p, stream);
     }
 }
 
 hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
-    // experiment knobs (environment): GMPI_TUNE_MINW 4|6 = waves/SIMD the register allocator targets,
-    // GMPI_TUNE_PF 1|2 = planes of prefetch, GMPI_TUNE_SKIP = ablation bits (see flags bits 16-19)
-    static const int tune = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 6; }();
-    static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 1; }();
+    // experiment knobs (environment): GMPI_TUNE_PF 1|2|3 = planes of prefetch, GMPI_TUNE_TW 32|64 = tile width,
+    // GMPI_TUNE_SKIP = ablation bits (see flags bits 16-19)
+    static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 2; }();
+    static const int tw = [] { const char* e = getenv("GMPI_TUNE_TW"); return e ? atoi(e) : kTileW; }();
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
     p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores, 8 = static loader map
-    if (tune == 4) return pf == 2 ? launch_lds_w<4, 2>(p, dtype, stream) : launch_lds_w<4, 1>(p, dtype, stream);
-    return pf == 2 ? launch_lds_w<6, 2>(p, dtype, stream) : launch_lds_w<6, 1>(p, dtype, stream);
+    if (tw == 64) return launch_lds_w<64, 6, 2>(p, dtype, stream);
+    switch (pf) {
+        case 1: return launch_lds_w<32, 6, 1>(p, dtype, stream);
+        case 3: return launch_lds_w<32, 6, 3>(p, dtype, stream);
+        default: return launch_lds_w<32, 6, 2>(p, dtype, stream);
+    }
 }
 
 }  // namespace gmpi
