@@ -5,31 +5,34 @@
 // TW x TH pixel tile (one pixel per thread) and walks the D planes front to back.  The warp is a
 // homography of a small rectangle, so the texels a tile needs on one plane form a small box whose
 // extremes are at the tile's four corner pixels.  The box is copied from HBM with 16-byte row loads
-// (each lane 4 consecutive texels of one channel row), kept as fp32 in LDS in [row][channel][x]
-// order with a per-plane pitch, and every pixel takes its 16 taps with 8 ds_read2_b32 (x0,x1 pairs).
+// (each lane 4 fp32 / 8 half-precision texels of one channel row), kept as fp32 in LDS in
+// [row][channel][x] order, and every pixel takes its 16 taps with 8 ds_read2_b32 (x0,x1 pairs).
 // Texels outside the texture are stored as zeros, so the consumer needs no masks ("zeros" padding of
-// F.grid_sample).  Two LDS buffers + register staging give a one-barrier-per-plane pipeline: loads
-// of plane k+1 are in flight while plane k is composited (a second prefetch stage costs registers --
-// spills at 3 workgroups/CU -- and gains nothing: profiles/r01_ablation.txt).
+// F.grid_sample).  Two LDS buffers + register staging give a one-barrier-per-plane pipeline: the loads
+// of plane k+1 are in flight while plane k is composited.  (Deeper staging is implemented -- PF template
+// parameter, GMPI_TUNE_PF -- but does not pay: the kernel is bound by its on-chip work, not by load
+// latency, and two planes in flight cost 25 % on the D = 256 workload: profiles/r01_ablation.txt.)
 //
 // Box size.  Tilted cameras shear and stretch the footprint: a 32x16 pixel tile needs 33x17 texels
-// for a frontal view, 37x20 at (yaw 0.3, pitch 0.1), 47x29 at the 2-sigma FFHQ pose (64-wide tiles
-// would need 91x38).  Hence 32-wide tiles, a box of up to 16 quads x 32 rows, and a capacity test in
-// floats (pitch is per plane) instead of fixed rows x columns.
+// for a frontal view, 37x20 at (yaw 0.3, pitch 0.1), 47x29 at the 2-sigma FFHQ pose.  Per chunk of
+// planes the tile is staged whole if every box fits the buffer, else as its two 32x8 halves, else
+// (texture much finer than the image, degenerate rays) the chunk takes the direct gather -- same
+// arithmetic, so results do not depend on the path.  64x8 tiles (TileCfg<64>, GMPI_TUNE_TW=64) read
+// longer lines but are no faster at any pose and far slower for tilted ones, so 32x16 is the default.
 //
-// The kernel is VALU-issue bound once the memory side is fixed (profiles/r01_lds_v0_*: HBM traffic
-// == algorithmic bytes), so the default (non-strict) path is written for instruction count: the three
-// IEEE divisions of the coordinate chain become mul+fma+fma against a correctly rounded reciprocal
-// that is hoisted out of the plane loop (1/ray_z per pixel) or computed once per plane (2/w, 2/h) --
-// see div_by_recip() in gmpi_device.hpp.
+// Instruction count is what bounds the kernel (HBM traffic == algorithmic bytes; with the memory loads
+// disabled it runs only 7 % (16-bit volumes) / 30 % (fp32) faster), so:
+//  * the three IEEE divisions of the coordinate chain are mul+fma+fma against correctly rounded
+//    reciprocals hoisted out of the plane loop (div_by_recip() in gmpi_device.hpp);
+//  * everything that is uniform per plane -- box origin address, in-texture ranges, plane constants -- is
+//    computed once per plane by one thread into an LDS table instead of 8x on the waves' scalar units;
+//  * the loader's thread -> item map is re-derived per chunk from the largest box of the chunk, so a frontal
+//    view needs 1 pass (16-bit) / 2 passes (fp32) over the box instead of the worst-case 2 / 3;
+//  * tap addresses are kept opaque so that the 8 ds_read2_b32 use immediate offsets.
 //
 // HBM traffic: each texel of the volume is read once per view (halo rows/columns are shared with the
 // neighbouring tiles through the XCD's L2: the blockIdx -> tile map gives every XCD a contiguous run
 // of tiles).  Algorithmic bytes: 16 B (fp32) / 8 B (bf16) per pixel*plane + 28-32 B per pixel.
-//
-// A chunk of planes in which some box exceeds the staging buffer (texture much finer than the image,
-// degenerate rays) takes the direct gather instead -- same arithmetic, so results do not depend on
-// the path.
 #include "gmpi_device.hpp"
 
 #include <cstdlib>
@@ -63,11 +66,14 @@ template <int TPI, int TW> struct LoaderCfg {
     static constexpr int kNL = (TileCfg<TW>::kMaxLines + kLinesPerPass - 1) / kLinesPerPass;  // 3 / 2 passes at most
 };
 
-// Per-plane record of the current chunk (LDS):
-//   tabI: qx0, by0 (box origin in texels, qx0 multiple of the item width), nq (items per row; < 0: box does not fit),
-//         nrows; both carry, in bits 8-15 / 16-23, the sub-range [lo, hi) of items / rows that lies inside the texture
-//   tabF: zdiff = d - eye_z, hw = w/2, hh = h/2
-//   tabG: RN(1/hw), RN(1/hh), 64-bit element offset of the box origin inside the MPI volume
+// Per-plane record of the current chunk (LDS), written once per plane by one thread so that the 8 waves do not repeat
+// the address arithmetic on their scalar units:
+//   tabL (loader):     byte address of the box origin (texel row by0, column qx0 of channel 0; qx0 a multiple of the item
+//                      width) as two dwords = words 0,1 of the plane's buffer descriptor; cols = nq | clo << 8 | ncol << 16;
+//                      lines = 4 nrows | llo << 8 | nline << 16.  nq items x nrows rows is the box; item columns
+//                      [clo, clo + ncol) and (row,channel) lines [llo, llo + nline) of it lie inside the texture
+//   tabF (compositor): zdiff = d - eye_z, hw = w/2, hh = h/2, RN(1/hw)
+//   tabG (compositor): RN(1/hh), qx0, by0
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     constexpr int TH = kNT / TW;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
-    int4* tabI = reinterpret_cast<int4*>(smem);
+    int4* tabL = reinterpret_cast<int4*>(smem);
     float4* tabF = reinterpret_cast<float4*>(smem + kChunk * 16);
     int4* tabG = reinterpret_cast<int4*>(smem + kChunk * 32);
     float* tile0 = reinterpret_cast<float*>(smem + kChunk * kRecBytes);
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     //      (16-bit) / 2 instead of 3 (fp32) passes -- the loader's VALU and request count shrink accordingly.
     int lcol = 0, lrowc = 0, perpass = kRowcPerPass, npass = kNL, dst_base = 0;
     bool loader = false;
+    bool slot_ok[kNL];  // the LDS slot of item r exists (lines past the box but inside the buffer are simply zero-filled)
     uint32_t g_off[kNL];  // BYTE offset of item r inside a plane, relative to the box origin (32-bit voffset)
     auto set_loader_map = [&](int cols, int max_rows) {
         // (integer division runs on the VALU: readfirstlane tells the compiler the results are wave-uniform, so the
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         for (int r = 0; r < kNL; ++r) {
             const int rowc = lrowc + r * perpass;
             g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) * static_cast<uint32_t>(sizeof(TexT));
+            slot_ok[r] = loader & (rowc < kMaxLines) & !(p.flags & (1u << 18));
         }
     };
 
@@ -222,7 +230,8 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                     finite = finite && (fabsf(ix) < 1e6f) && (fabsf(iy) < 1e6f);  // false for NaN too
                     mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
                 }
-                int4 ri = make_int4(0, 0, -1, 0);
+                int4 ri = make_int4(0, 0, -1, 0);  // qx0, by0, nq (< 0: does not fit), nrows
+                int cols = 0, lines = 0;
                 if (finite) {
                     const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
                     const int by0 = static_cast<int>(floorf(mny - kBoxEps)), by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
@@ -235,18 +244,17 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                     } else {  // (qx0 and Wt are multiples of the item width)
                         const int clo = min(max(-ri.x / TPI, 0), ri.z), chi = min(max((Wt - ri.x) / TPI, 0), ri.z);
                         const int rlo = min(max(-by0, 0), ri.w), rhi = min(max(Ht - by0, 0), ri.w);
-                        ri.z |= clo << 8 | chi << 16;
-                        ri.w |= rlo << 8 | rhi << 16;
+                        cols = ri.z | clo << 8 | (chi - clo) << 16;
+                        lines = 4 * ri.w | 4 * rlo << 8 | 4 * (rhi - rlo) << 16;
                     }
                 }
-                nq_bits |= ri.z < 0 ? 0x80000000u : 1u << (ri.z & 31);
+                nq_bits |= ri.z < 0 ? 0x80000000u : 1u << ri.z;
                 row_bits |= 1u << (ri.w & 31);
                 const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
-                const int64_t goff = static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(ri.y) * s_row + ri.x;
-                tabI[t] = ri;
-                tabF[t] = make_float4(zdiff, hw, hh, 0.f);
-                tabG[t] = make_int4(__float_as_int(1.0f / hw), __float_as_int(1.0f / hh), static_cast<int>(goff & 0xffffffff),
-                                    static_cast<int>(goff >> 32));
+                const uint64_t origin = reinterpret_cast<uint64_t>(vol + (static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(ri.y) * s_row + ri.x));
+                tabL[t] = make_int4(static_cast<int>(origin & 0xffffffffu), static_cast<int>((origin >> 32) & 0xffffu), cols, lines);
+                tabF[t] = make_float4(zdiff, hw, hh, 1.0f / hw);
+                tabG[t] = make_int4(__float_as_int(1.0f / hh), ri.x, ri.y, 0);
             }
             const uint32_t a = __builtin_amdgcn_readfirstlane(__ockl_wgred_or_i32(static_cast<int>(nq_bits)));  // also publishes the table
             const uint32_t b = __builtin_amdgcn_readfirstlane(__ockl_wgred_or_i32(static_cast<int>(row_bits)));
@@ -273,7 +281,6 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // One buffer resource per plane (its 4 channel images); items that fall outside the box or outside the
         // texture get the offset 0x80000000, which the hardware range check turns into zeros without touching
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
-        const uint32_t plane_bytes = static_cast<uint32_t>((3 * s_chan + static_cast<int64_t>(Ht - 1) * s_row + Wt) * sizeof(TexT));
         // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
         auto issue_loads = [&](auto np, int t, u32x4 (&L)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;  // passes of this chunk's loader map (compile-time: see run_staged)
@@ -281,51 +288,42 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             // memory access): hipcc's waitcnt insertion only lets a load stay in flight across the next plane's
             // staged store ("vmcnt(NP)" instead of "vmcnt(0)") if every path issues the same number of loads.
             const bool live = (t < kn) & !(p.flags & (1u << 16));
-            t = min(t, kn - 1);
-            const int4 ri = tabI[t];
-            const int qx0 = __builtin_amdgcn_readfirstlane(ri.x), by0 = __builtin_amdgcn_readfirstlane(ri.y);
-            const int cz = __builtin_amdgcn_readfirstlane(ri.z), rw = __builtin_amdgcn_readfirstlane(ri.w);
+            const int4 rl = tabL[min(t, kn - 1)];
             // the descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a waterfall loop
-            // (cdna_hip_programming.md T20): pass its inputs through readfirstlane
-            const uint64_t pa = reinterpret_cast<uint64_t>(vol + static_cast<int64_t>(kc + t) * s_plane);
-            const uint32_t pa_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pa >> 32)));
-            const uint32_t pa_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(pa & 0xffffffffu)));
-            const uint64_t pu = (static_cast<uint64_t>(pa_hi) << 32) | pa_lo;  // (readfirstlane returns int: widen unsigned)
+            // (cdna_hip_programming.md T20): pass its inputs through readfirstlane.  Base = the box origin, so the
+            // per-lane offsets are the chunk-invariant g_off[]; num_records 2^31: only the explicit out-of-range
+            // offset below is rejected (every other lane is inside the texture by the range tests)
+            const uint32_t b_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rl.x));
+            const uint32_t b_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(rl.y));
+            const int cols = __builtin_amdgcn_readfirstlane(rl.z), lines = __builtin_amdgcn_readfirstlane(rl.w);
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<void*>(pu), 0, __builtin_amdgcn_readfirstlane(static_cast<int>(plane_bytes)), 0x00020000);
-            const uint32_t origin = static_cast<uint32_t>(by0 * static_cast<int>(s_row) + qx0) * static_cast<uint32_t>(sizeof(TexT));
-            // item columns [clo, chi) and lines [4 rlo, 4 rhi) of the box lie inside the texture (one unsigned compare
-            // each); everything else reads as zero ("zeros" padding) without touching memory
-            const int clo = (cz >> 8) & 0xff, ncol = ((cz >> 16) & 0xff) - clo;
-            const int llo = 4 * ((rw >> 8) & 0xff), nline = 4 * ((rw >> 16) & 0xff) - llo;
+                reinterpret_cast<void*>((static_cast<uint64_t>(b_hi) << 32) | b_lo), 0, static_cast<int>(0x80000000u), 0x00020000);
+            // item columns [clo, clo+ncol) and lines [llo, llo+nline) of the box lie inside the texture (one unsigned
+            // compare each); everything else reads as zero ("zeros" padding) without touching memory
+            const int clo = (cols >> 8) & 0xff, ncol = (cols >> 16) & 0xff;
+            const int llo = (lines >> 8) & 0xff, nline = (lines >> 16) & 0xff;
             const bool col_ok = loader & live & (static_cast<unsigned>(lcol - clo) < static_cast<unsigned>(ncol));
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 const bool ok = col_ok & (static_cast<unsigned>(lrowc + (r * perpass - llo)) < static_cast<unsigned>(nline));
-                const uint32_t off = ok ? origin + g_off[r] : 0x80000000u;  // >= num_records (< 2^31); off+15 cannot wrap
+                const uint32_t off = ok ? g_off[r] : 0x80000000u;  // == num_records: rejected; off+15 cannot wrap
                 L[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
             }
         };
-        auto store_box = [&](auto np, int t, float* tile, u32x4 (&L)[decltype(np)::value]) {
+        auto store_box = [&](auto np, float* tile, u32x4 (&L)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;
-            const bool live = (t < kn) & !(p.flags & (1u << 18));
-            const int4 ri = tabI[min(t, kn - 1)];
-            const int nq = __builtin_amdgcn_readfirstlane(ri.z) & 0xff;
-            const int nrowc = (__builtin_amdgcn_readfirstlane(ri.w) & 0xff) * 4;
             // LDS slot of item r: line (lrowc + perpass*r), floats [TPI*lcol, TPI*lcol + TPI)
             float4* dst = reinterpret_cast<float4*>(tile) + dst_base;
             const int pass_stride = perpass * (kPitch / 4);
-            const bool col_ok = loader & (lcol < nq) & live;
             uint32_t mx = 0;  // max of the fp32 bit patterns staged by this lane (lanes outside the box hold zeros)
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 float4 q[TPI / 4];
                 Q::cvt(L[r], q);
-                const bool ok = col_ok & (lrowc + r * perpass < nrowc);
 #pragma unroll
                 for (int h = 0; h < TPI / 4; ++h) {
                     mx = max(max(mx, __float_as_uint(q[h].x)), max(max(__float_as_uint(q[h].y), __float_as_uint(q[h].z)), __float_as_uint(q[h].w)));
-                    if (ok) dst[r * pass_stride + h] = q[h];
+                    if (slot_ok[r]) dst[r * pass_stride + h] = q[h];
                 }
             }
             // [0,1] test on bit patterns: non-negative floats order like unsigned ints, so v in [0,1] <=> bits <=
@@ -344,7 +342,6 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
 
         auto composite = [&](int t, const float* __restrict__ tile, bool mine) {
             if (!mine | ((p.flags & (1u << 17)) != 0)) return;
-            const int4 ri = tabI[t];
             const float4 rf = tabF[t];
             const int4 rg = tabG[t];
             float ix, iy, s;
@@ -354,7 +351,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 plane_coord<AC>(rf.x, rf.z + rf.z, rf.y + rf.y, ex, ey, rx, ry, rz, cx, cy, ix, iy, s, u, v);
                 f = footprint(ix, iy, Ht, Wt);
             } else {
-                plane_coord_recip<AC>(rf.x, rf.y, rf.z, __int_as_float(rg.x), __int_as_float(rg.y), ex, ey, rx, ry, rz, rcp_rz, cx,
+                plane_coord_recip<AC>(rf.x, rf.y, rf.z, rf.w, __int_as_float(rg.x), ex, ey, rx, ry, rz, rcp_rz, cx,
                                       cy, ix, iy, s);
                 // ATen's vectorised CPU form of the weights: e = 1 - w (equals x1 - ix unless ix < 0)
                 const float wx1 = ix - floorf(ix), wy1 = iy - floorf(iy);
@@ -363,7 +360,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             }
             // the box contains every tap of the tile (corner argument above); the integer corner is taken from the
             // floor directly (Footprint::x0/y0 carry the gather path's out-of-range sentinel)
-            const int lx = static_cast<int>(floorf(ix)) - ri.x, ly = static_cast<int>(floorf(iy)) - ri.y;
+            const int lx = static_cast<int>(floorf(ix)) - rg.y, ly = static_cast<int>(floorf(iy)) - rg.z;
             // unsigned + clamped: keeps wild coordinates (NaN rays) inside the buffer and proves the base non-negative,
             // so the 8 tap-pair reads become ds_read2_b32 with immediate offsets
             const uint32_t idx = min(static_cast<uint32_t>(__mul24(ly, 4 * kPitch) + lx), static_cast<uint32_t>(kCapFloats - 7 * kPitch - 2));
@@ -398,7 +395,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     #pragma unroll
                 for (int u = 0; u < PFX; ++u) {
                     float* tile = tile0 + ((t + u) & 1) * kCapFloats;
-                    store_box(np, t + u, tile, L[u]);
+                    store_box(np, tile, L[u]);
                     __syncthreads();  // box t+u visible; everybody is done reading box t+u-1 (the other buffer)
                     issue_loads(np, t + u + PFX, L[u]);  // in flight while the PFX planes before it are composited
                     composite(t + u, tile, mine & (t + u < kn));
@@ -508,12 +505,12 @@ static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) 
 hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
     // experiment knobs (environment): GMPI_TUNE_PF 1|2|3 = planes of prefetch, GMPI_TUNE_TW 32|64 = tile width,
     // GMPI_TUNE_SKIP = ablation bits (see flags bits 16-19)
-    static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 2; }();
+    static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 1; }();
     static const int tw = [] { const char* e = getenv("GMPI_TUNE_TW"); return e ? atoi(e) : kTileW; }();
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
     p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores, 8 = static loader map
-    if (tw == 64) return launch_lds_w<64, 6, 2>(p, dtype, stream);
+    if (tw == 64) return launch_lds_w<64, 6, 1>(p, dtype, stream);
     switch (pf) {
         case 1: return launch_lds_w<32, 6, 1>(p, dtype, stream);
         case 3: return launch_lds_w<32, 6, 3>(p, dtype, stream);
