@@ -1,0 +1,81 @@
+"""GPU parity tests aimed at the staging paths of the LDS kernel (ml-gmpi_amd/csrc/render_lds.hip): chunk
+boundaries and padding planes, the half-tile staging of tilted views, the in-kernel gather fallback, the loader-map
+pass counts, and the experiment knobs (prefetch depth, 64-pixel-wide tiles, static loader map).  Strict-order mode
+must stay BIT-EXACT against the oracle on every path; the default mode within the 1e-5 bar."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from test_hip_parity import TOL, _random_case, hip_render
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check(rgba, dhw, ray, eye, zd, variant="lds"):
+    orc = oracle.render(rgba, dhw, ray, eye, zd, threads=True)
+    strict = hip_render(rgba, dhw, ray, eye, zd, variant=variant, strict=True)
+    for k in ("color", "depth", "T"):
+        assert np.array_equal(strict[k], orc[k]), (k, np.abs(strict[k] - orc[k]).max())
+    fast = hip_render(rgba, dhw, ray, eye, zd, variant=variant)
+    assert np.abs(fast["color"] - orc["color"]).max() <= 0.5 * TOL
+    assert np.abs(fast["depth"] - orc["depth"]).max() <= TOL
+    assert np.abs(fast["T"] - orc["T"]).max() <= TOL
+
+
+@pytest.mark.parametrize("D", [1, 2, 95, 96, 97, 193])
+def test_chunk_boundaries_and_padding_planes(D):
+    """The plane loop runs in chunks of 96 planes, padded to a multiple of the prefetch depth."""
+    _check(*_random_case(seed=20 + D, B=1, D=D, S=64))
+
+
+def test_tilted_views_take_the_half_tile_path():
+    """2-sigma FFHQ poses at 256^2: the 32x16 tile boxes exceed the staging buffer on some planes -> 32x8 halves."""
+    _check(*_random_case(seed=31, B=4, D=12, S=256, extreme=True))
+
+
+@pytest.mark.parametrize("S,T", [(32, 256), (48, 512)])
+def test_texture_much_finer_than_image_falls_back_to_gather_inside_the_kernel(S, T):
+    """8-10 texels per pixel: not even a half tile fits -> the chunk is gathered from global memory, same arithmetic."""
+    _check(*_random_case(seed=32, B=2, D=5, S=S, T=T))
+
+
+@pytest.mark.parametrize("S,T", [(256, 64), (128, 96), (64, 256)])
+def test_image_finer_or_coarser_than_texture(S, T):
+    """Box widths from a few texels (1 loader pass) to the buffer limit (2-3 passes), fp32 and 16-bit items."""
+    rgba, dhw, ray, eye, zd = _random_case(seed=33, B=2, D=7, S=S, T=T)
+    _check(rgba, dhw, ray, eye, zd)
+    stored = rgba.to(torch.bfloat16)
+    orc = oracle.render(stored.float(), dhw, ray, eye, zd)
+    out = hip_render(stored, dhw, ray, eye, zd, variant="lds", strict=True)
+    assert np.array_equal(out["color"], orc["color"]) and np.array_equal(out["depth"], orc["depth"])
+
+
+_KNOB_SCRIPT = r"""
+import sys, numpy as np, torch
+for d in ("", "/oracle", "/tests"): sys.path.insert(0, sys.argv[1] + d)
+import oracle
+from test_hip_parity import _random_case, hip_render
+for cfg in (dict(seed=41, B=2, D=9, S=128), dict(seed=42, B=2, D=5, S=128, extreme=True), dict(seed=43, B=1, D=97, S=64)):
+    rgba, dhw, ray, eye, zd = _random_case(**cfg)
+    for vol in (rgba, rgba.to(torch.bfloat16)):
+        orc = oracle.render(vol.float(), dhw, ray, eye, zd)
+        out = hip_render(vol, dhw, ray, eye, zd, variant="lds", strict=True)
+        for k in ("color", "depth", "T"):
+            assert np.array_equal(out[k], orc[k]), (cfg, vol.dtype, k, float(np.abs(out[k] - orc[k]).max()))
+print("KNOBS-OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{"GMPI_TUNE_PF": "2"}, {"GMPI_TUNE_PF": "3"}, {"GMPI_TUNE_TW": "64"},
+                                 {"GMPI_TUNE_SKIP": "8"}])
+def test_experiment_knobs_keep_bit_exactness(env):
+    """The knobs are read once per process, hence a subprocess per setting."""
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT, ROOT], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "KNOBS-OK" in r.stdout, (env, r.stdout[-2000:], r.stderr[-2000:])
