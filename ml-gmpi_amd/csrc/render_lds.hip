@@ -139,8 +139,20 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile_id >= n_tiles) return;
     const int tiles_per_view = tiles_x * tiles_y;
-    const int n = tile_id / tiles_per_view;
-    const int trem = tile_id - n * tiles_per_view;
+    // Views that share one MPI (video paths: views_per_mpi > 1) are interleaved per tile position, so the workgroups
+    // that need (nearly) the same texels of a plane run next to each other in time and on the same XCD: the volume is
+    // then read from HBM about once per group of views instead of once per view (the rest hits in that XCD's L2).
+    int n, trem;
+    if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) {
+        const int group = tile_id / (tiles_per_view * p.views_per_mpi);           // full groups come first
+        const int first = group * p.views_per_mpi, size = min(p.views_per_mpi, p.N - first);
+        const int r = tile_id - first * tiles_per_view;
+        trem = r / size;
+        n = first + (r - trem * size);
+    } else {
+        n = tile_id / tiles_per_view;
+        trem = tile_id - n * tiles_per_view;
+    }
     const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
 
     const int tid = threadIdx.x;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     const int64_t s_chan = p.s_chan, s_row = p.s_row, s_plane = p.s_plane;
 
     uint32_t bad = 0;
-    if (p.status != nullptr && tile_id == n * tiles_per_view && tid == 0) {  // mpi.py:70-72, once per view
+    if (p.status != nullptr && trem == 0 && tid == 0) {  // mpi.py:70-72, once per view
         const float ez0 = p.eye_pos[2];
         bool behind = false;
         for (int k = 0; k < D; ++k) behind |= !(dhw[3 * k] >= ez0);
