@@ -112,7 +112,10 @@ int gmpi_mpi_render_launch(const GmpiRenderParams *params, void *stream);
 /*
  * Gradient of the render w.r.t. the RGBA volume -- what autograd computes when the reference's G-step
  * back-propagates through MPIRenderer.render (gmpi/train.py:740-779; the sampling grid carries no gradient,
- * mpi.py:65).  `params` are the forward's parameters (outputs may be NULL); grad_rgb [N,3,H,W] is the gradient
+ * mpi.py:65).  `params` are the forward's parameters; rgb_out / depth_out may be NULL; transmittance_out, when not
+ * NULL, must still hold what the forward wrote (the sweep runs back to front from it; without it every pixel first
+ * re-walks the alpha channel).  variant GATHER selects the one-pixel-per-lane kernel (16 global atomics per
+ * pixel*plane), anything else the tile kernel that stages the scatter in LDS.  grad_rgb [N,3,H,W] is the gradient
  * w.r.t. the colour the forward wrote (the OUT_PM1 factor 2 is applied inside when that flag is set); grad_depth
  * [N,1,H,W] or NULL; grad_rgba [M,D,4,Ht,Wt] fp32 with the given element strides (innermost 1) is ACCUMULATED into
  * (atomicAdd) -- the caller zero-fills it.

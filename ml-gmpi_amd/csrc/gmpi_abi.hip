@@ -9,7 +9,7 @@ namespace gmpi {
 hipError_t launch_gather(const KParams& p, int dtype, hipStream_t stream);  // render_gather.hip
 hipError_t launch_lds(const KParams& p, int dtype, hipStream_t stream);     // render_lds.hip
 hipError_t launch_backward(const KParams& p, int dtype, const float* g_rgb, const float* g_depth, float* g_rgba,
-                           const int64_t* gstride, hipStream_t stream);    // render_backward.hip
+                           const int64_t* gstride, bool tiles, hipStream_t stream);  // render_backward.hip
 bool lds_variant_supports(const KParams& p, int dtype);                     // render_lds.hip
 int lds_variant_query(int what);                                            // render_lds.hip
 
@@ -227,7 +227,7 @@ int gmpi_mpi_render_backward_launch(const GmpiRenderParams* params, const float*
     for (int i = 0; i < 4; ++i)
         if (grad_rgba_stride[i] <= 0 && !(i == 0 && params->M == 1)) return GMPI_E_STRIDE;
     return hip_rc(launch_backward(p, params->rgba_dtype, grad_rgb, grad_depth, grad_rgba, grad_rgba_stride,
-                                  static_cast<hipStream_t>(stream)));
+                                  params->variant != GMPI_VARIANT_GATHER, static_cast<hipStream_t>(stream)));
 }
 
 int gmpi_last_plane_uv_minmax_launch(const GmpiRenderParams* params, float* uv_minmax, void* stream) {

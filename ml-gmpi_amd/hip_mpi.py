@@ -260,10 +260,13 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgba, mpi, dhw, ray_dir, eye_pos, z_dir, kwargs):
-        res = mpi.render_views(rgba.detach(), dhw, ray_dir, eye_pos, z_dir, _in_autograd_fn=True, **kwargs)
+        # the backward starts from the final transmittance, so the forward always writes it
+        res = mpi.render_views(rgba.detach(), dhw, ray_dir, eye_pos, z_dir, _in_autograd_fn=True,
+                               **dict(kwargs, want_transmittance=True))
         ctx.params, ctx.keep = res.pop("_bwd")
         ctx.rgba_dtype, ctx.rgba_shape = rgba.dtype, tuple(rgba.shape)
-        T = res["T"] if res["T"] is not None else res["depth"].new_empty(0)
+        T = res["T"]
+        ctx.t_final = T  # (kept alive: ctx.params holds its raw pointer)
         ctx.mark_non_differentiable(res["status"], T)  # gradient w.r.t. the transmittance output is not provided
         return res["color"], res["depth"], T, res["status"]
 

@@ -33,6 +33,10 @@ def _ref_grads(rgba, dhw, ray, eye, zd, v2m, gc, gd, ac):
     dict(N=2, M=2, D=6, Ht=24, Wt=28, H=20, W=22, ac=True),
     dict(N=3, M=1, D=5, Ht=16, Wt=16, H=33, W=17, ac=False),        # several views of one MPI accumulate into one gradient
     dict(N=2, M=2, D=8, Ht=64, Wt=64, H=64, W=64, ac=True, variant="lds"),
+    dict(N=2, M=2, D=8, Ht=64, Wt=64, H=64, W=64, ac=True, variant="gather"),      # one pixel per lane, global atomics only
+    dict(N=2, M=1, D=98, Ht=48, Wt=48, H=40, W=72, ac=True),                       # two table chunks, ragged tiles
+    dict(N=1, M=1, D=3, Ht=256, Wt=256, H=24, W=24, ac=False, fwd_tol=1e-4, bwd_tol=1e-4, rel_tol=2e-2),       # minified: boxes do not fit -> direct scatter
+                                                                                   # (10 texels/pixel of white noise: fp32 vs float64 coordinates)
 ])
 def test_backward_matches_autograd(cfg):
     from ml_gmpi_amd import MPI
@@ -49,15 +53,43 @@ def test_backward_matches_autograd(cfg):
     mpi = MPI(align_corners=ac, variant=cfg.get("variant", "auto"), on_out_of_plane="raise")
     out = mpi.render_views(vol, t(dhw), t(ray), t(eye), t(zd), view_to_mpi=t(v2m.astype(np.int32)), check_last_plane=False)
     assert out["color"].requires_grad and out["depth"].requires_grad
-    assert np.abs(out["color"].detach().cpu().numpy() - ref_c).max() <= 1e-5
+    assert np.abs(out["color"].detach().cpu().numpy() - ref_c).max() <= cfg.get("fwd_tol", 1e-5)
     loss = (out["color"] * t(gc)).sum() + (out["depth"] * t(gd)).sum()
     loss.backward()
     got = vol.grad.cpu().numpy()
     scale = np.abs(ref_g).max()
-    assert np.abs(got - ref_g).max() <= 2e-5 * scale + 1e-6, (np.abs(got - ref_g).max(), scale)
+    assert np.abs(got - ref_g).max() <= cfg.get("bwd_tol", 2e-5) * scale + 1e-6, (np.abs(got - ref_g).max(), scale)
     # relative check on the significant entries
     big = np.abs(ref_g) > 1e-3 * scale
-    assert np.max(np.abs(got[big] - ref_g[big]) / np.abs(ref_g[big])) <= 2e-3
+    assert np.max(np.abs(got[big] - ref_g[big]) / np.abs(ref_g[big])) <= cfg.get("rel_tol", 2e-3)
+
+
+def test_backward_behind_opaque_and_nearly_opaque_planes():
+    """alpha == 1 (om = 1e-10) and 1 - 1e-6 in the middle of the stack: dL/da of such a texel is the O(1) quantity
+    (sum of the 1e-10-scaled weights behind it) / om; a front-to-back difference of sums loses it, torch's cumprod
+    backward (reverse cumsum) does not.  Also four exactly opaque planes in a row (final T underflows in fp32)."""
+    from ml_gmpi_amd import MPI
+    N = M = 1
+    D, S = 8, 32
+    rgba, dhw, ray, eye, zd, v2m = _setup(N, M, D, S, S, S, S, seed=47)
+    rgba[:, 2, 3, :, : S // 2] = 1.0
+    rgba[:, 4, 3, :, S // 4:] = 1.0 - 1e-6
+    rgba[:, 3:7, 3, : S // 3, :] = 1.0
+    g = np.random.default_rng(6)
+    gc = g.standard_normal((N, 3, S, S)).astype(np.float32)
+    gd = g.standard_normal((N, 1, S, S)).astype(np.float32)
+    _, _, ref_g = _ref_grads(rgba, dhw, ray, eye, zd, v2m, gc, gd, True)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for variant in ("auto", "gather"):
+        vol = t(rgba).requires_grad_(True)
+        mpi = MPI(align_corners=True, variant=variant, on_out_of_plane="raise")
+        out = mpi.render_views(vol, t(dhw), t(ray), t(eye), t(zd), view_to_mpi=t(v2m.astype(np.int32)), check_last_plane=False)
+        ((out["color"] * t(gc)).sum() + (out["depth"] * t(gd)).sum()).backward()
+        got = vol.grad.cpu().numpy()
+        scale = np.abs(ref_g).max()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref_g).max() <= 1e-4 * scale, (variant, np.abs(got - ref_g).max(), scale)
 
 
 def test_backward_through_renderer_render_pm1_and_expand():
