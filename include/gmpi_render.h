@@ -174,6 +174,24 @@ int gmpi_alpha_depth_launch(const void *alpha, int32_t alpha_dtype, int64_t stri
                             const float *plane_ds, int32_t B, int32_t D, int32_t H, int32_t W, float *depth_out,
                             float *transmittance_out, void *stream);
 
+/*
+ * The rest of the reference's shading augmentation (gmpi/core/light_renderer.py `LightRenderer.render`), after
+ * gmpi_alpha_depth_launch:
+ *  - gmpi_light_blur_launch: torchvision GaussianBlur of the depth images [B,H,W] (light_renderer.py:51-55,109):
+ *    reflect padding, 2-D kernel = outer product of `kernel1d` [ksize] (ksize odd, ksize/2 < H, W).
+ *  - gmpi_light_shading_launch: point cloud of the blurred depth along the last plane's texel rays (compute_pcl
+ *    :102-120; xyz_last [H,W,3] contiguous), normals from the four neighbour cross products with replicate padding
+ *    (get_normal :57-80), Lambert term against light_dir [B,3] (unit vectors), shading[b,y,x] = ka + kd * max(-n.l, 0).
+ *  - gmpi_light_apply_launch: out[b,k,0:3] = clip(rgba[b,k,0:3] * shading[b], 0, 1), out[b,k,3] = rgba[b,k,3]
+ *    (:193-198).  rgba [B,D,4,H,W] with element strides (innermost 1), any storage dtype; out fp32 contiguous.
+ */
+int gmpi_light_blur_launch(const float *depth, float *blurred, int32_t B, int32_t H, int32_t W, const float *kernel1d,
+                           int32_t ksize, void *stream);
+int gmpi_light_shading_launch(const float *depth_blurred, const float *xyz_last, const float *light_dir, float ka, float kd,
+                              int32_t B, int32_t H, int32_t W, float *shading, void *stream);
+int gmpi_light_apply_launch(const void *rgba, int32_t rgba_dtype, const int64_t *rgba_stride, const float *shading, float *out,
+                            int32_t B, int32_t D, int32_t H, int32_t W, void *stream);
+
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
  * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height.  Unknown -> -1.      */
 int gmpi_query(int32_t what);

@@ -4,11 +4,11 @@ from .hip_mpi import MPI, HipMPI
 from .renderer import MPIRenderer, PRESETS, make_renderer
 from .driver import ViewBatchDriver, shard_views, render_views_sharded, frames_to_uint8
 from .install import install, uninstall
-from .light import compute_depth
+from .light import LightRenderer, compute_depth
 
 __all__ = [
     "GmpiError", "build_extension", "library_path", "load_library",
     "MPI", "HipMPI", "MPIRenderer", "PRESETS", "make_renderer",
     "ViewBatchDriver", "shard_views", "render_views_sharded", "frames_to_uint8",
-    "install", "uninstall", "compute_depth",
+    "install", "uninstall", "compute_depth", "LightRenderer",
 ]

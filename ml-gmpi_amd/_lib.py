@@ -28,6 +28,9 @@ EXPORTS = (
     "gmpi_frames_to_uint8_launch",
     "gmpi_generate_rays_launch",
     "gmpi_alpha_depth_launch",
+    "gmpi_light_blur_launch",
+    "gmpi_light_shading_launch",
+    "gmpi_light_apply_launch",
     "gmpi_query",
     "gmpi_version_string",
 )
@@ -113,6 +116,14 @@ def load_library():
     lib.gmpi_alpha_depth_launch.restype = ctypes.c_int
     lib.gmpi_alpha_depth_launch.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp,
                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, vp, vp]
+    lib.gmpi_light_blur_launch.restype = ctypes.c_int
+    lib.gmpi_light_blur_launch.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int32, vp]
+    lib.gmpi_light_shading_launch.restype = ctypes.c_int
+    lib.gmpi_light_shading_launch.argtypes = [vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_int32,
+                                              ctypes.c_int32, vp, vp]
+    lib.gmpi_light_apply_launch.restype = ctypes.c_int
+    lib.gmpi_light_apply_launch.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), vp, vp, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     lib.gmpi_query.restype = ctypes.c_int
     lib.gmpi_query.argtypes = [ctypes.c_int32]
     lib.gmpi_version_string.restype = ctypes.c_char_p

@@ -202,11 +202,87 @@ def run_light_depth():
     print("wrote light_compute_depth", tuple(depth.shape))
 
 
+def _torchvision_stand_in():
+    """torchvision is not installed in this image.  `LightRenderer.__init__` only needs
+    torchvision.transforms.GaussianBlur(kernel_size, sigma); the stand-in restates torchvision's functional
+    `gaussian_blur` (transforms/_functional_tensor.py): 1-D kernels = pdf samples on linspace(-(k-1)/2, (k-1)/2, k)
+    normalised to 1, 2-D kernel = their outer product, reflect padding by k//2, depthwise conv2d.  Everything else on
+    the path (compute_depth, compute_pcl, get_normal, the shading and the pose sampling) is the reference's own code."""
+    import types
+
+    class GaussianBlur(torch.nn.Module):
+        def __init__(self, kernel_size, sigma):
+            super().__init__()
+            self.kernel_size, self.sigma = tuple(kernel_size), tuple(sigma)
+
+        @staticmethod
+        def _k1d(k, s):
+            lim = (k - 1) * 0.5
+            x = torch.linspace(-lim, lim, steps=k)
+            pdf = torch.exp(-0.5 * (x / s).pow(2))
+            return pdf / pdf.sum()
+
+        def forward(self, img):
+            kx, ky = self._k1d(self.kernel_size[0], self.sigma[0]), self._k1d(self.kernel_size[1], self.sigma[1])
+            k2d = torch.mm(ky[:, None], kx[None, :]).to(img.dtype)
+            c = img.shape[-3]
+            k2d = k2d.expand(c, 1, k2d.shape[0], k2d.shape[1])
+            pad = [self.kernel_size[0] // 2, self.kernel_size[0] // 2, self.kernel_size[1] // 2, self.kernel_size[1] // 2]
+            return torch.nn.functional.conv2d(torch.nn.functional.pad(img, pad, mode="reflect"), k2d, groups=c)
+
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.SimpleNamespace(GaussianBlur=GaussianBlur)
+    return tv
+
+
+def run_light_render():
+    """LightRenderer.render (light_renderer.py:122-199) on a small MPI: the reference class end to end (seeded light
+    pose), with the torchvision stand-in above for the blur."""
+    import importlib
+    sys.modules["torchvision"] = _torchvision_stand_in()
+    sys.modules.pop("gmpi.core.light_renderer", None)
+    if ref_import.REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, ref_import.REFERENCE_ROOT)
+    ns = ref_import.import_reference()
+    lr = importlib.import_module("gmpi.core.light_renderer")
+    B, D, S = 2, 6, 32
+    r = ref_import.make_reference_renderer(ns, "FFHQ", D)
+    xyz, _ = r.get_xyz(S, S, ret_single_res=True)  # [D,S,S,3]
+    rgba = oracle.synth_rgba(79, (B, D, 4, S, S), last_alpha_one=True)
+    # smooth alpha so that the surface (and its normals) are not pure noise
+    a = torch.from_numpy(rgba[:, :, 3:4].reshape(B * D, 1, S, S))
+    a = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(a, (3, 3, 3, 3), mode="replicate"), 7, stride=1)
+    rgba[:, :, 3] = a.reshape(B, D, S, S).numpy()
+    rgba[:, -1, 3] = 1.0
+    out = {}
+    for name, kw, steps in (("kd", dict(ka_max=0.6, kd_max=0.9, n_grow_iters=4), 3), ("ambient", dict(ka_max=1.0, kd_max=0.0, n_grow_iters=2), 2)):
+        L = lr.LightRenderer(sphere_center_z=1.0, sphere_r=1.0, **kw)
+        torch.manual_seed(123)
+        res = None
+        for _ in range(steps):  # `step` ramps ka/kd (light_renderer.py:176-179)
+            res = L.render(torch.from_numpy(rgba), r.static_mpi_plane_dhws, xyz)
+        out[f"ref_{name}"] = res.numpy()
+        torch.manual_seed(123)  # the light direction of the LAST step, re-derived with the reference's own sampler
+        for _ in range(steps):
+            c2w, _, _ = ns.cam_utils.gen_sphere_path(n_cams=B, sphere_center=L.sphere_center, sphere_r=L.sphere_r,
+                                                     yaw_mean=L.l_h_mean, yaw_std=L.l_h_std, pitch_mean=L.l_v_mean,
+                                                     pitch_std=L.l_v_std, n_truncated_stds=2, flag_rnd=True,
+                                                     sample_method="truncated_gaussian", given_yaws=None, given_pitches=None)
+        pos = torch.as_tensor(c2w[:, :3, 3], dtype=torch.float32)
+        out[f"light_dir_{name}"] = ns.torch_utils.normalize_vecs(torch.FloatTensor(L.sphere_center).reshape(1, 3) - pos).numpy()
+        out[f"ka_kd_{name}"] = np.array([L.cur_ka, L.cur_kd], dtype=np.float64)
+        out[f"rng_after_{name}"] = torch.rand(2).numpy()
+    np.savez(os.path.join(OUT, "light_render.npz"), meta=json.dumps(dict(seed=79, B=B, D=D, S=S)), rgba=rgba,
+             dhw=r.static_mpi_plane_dhws.numpy(), xyz=xyz.numpy(), **out)
+    print("wrote light_render", {k: v.shape for k, v in out.items()})
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "light":
         os.makedirs(OUT, exist_ok=True)
         torch.set_num_threads(1)
         run_light_depth()
+        run_light_render()
         return
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
@@ -216,6 +292,7 @@ def main():
     run_multiview_case(ns)
     run_geometry(ns)
     run_light_depth()
+    run_light_render()
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by oracle/make_golden.py from the reference at /root/reference "
                 "(apple/ml-gmpi @ 2024_08_07), CPU fp32, torch %s, numpy %s.\n" % (torch.__version__, np.__version__))

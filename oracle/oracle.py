@@ -131,6 +131,48 @@ def alpha_depth(mpi_alpha, plane_ds):
     return depth, T
 
 
+def gaussian_kernel1d(ksize: int, sigma: float) -> np.ndarray:
+    """torchvision.transforms.functional `_get_gaussian_kernel1d`, float32 step by step."""
+    lim = np.float32((ksize - 1) * 0.5)
+    x = np.linspace(-lim, lim, ksize, dtype=np.float32)
+    pdf = np.exp(np.float32(-0.5) * (x / np.float32(sigma)) ** 2).astype(np.float32)
+    return (pdf / pdf.sum(dtype=np.float32)).astype(np.float32)
+
+
+def light_shade(rgba, plane_ds, xyz_last, light_dir, ka, kd, ksize=9, sigma=None):
+    """LightRenderer.render (light_renderer.py:122-199) restated in numpy float32 for a GIVEN light direction [B,3]:
+    compute_depth (:82-100) -> GaussianBlur (reflect padding, :51-55) -> compute_pcl (:102-120) -> get_normal (:57-80)
+    -> diffuse = clamp(-n.l, 0), shading = ka + kd*diffuse (:163-190) -> clip(rgb*shading, 0, 1) | alpha (:193-198)."""
+    f = np.float32
+    rgba = _f32(rgba)
+    B, D, _, H, W = rgba.shape
+    depth, _ = alpha_depth(rgba[:, :, 3:], plane_ds)
+    if sigma is None:
+        sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    k1 = gaussian_kernel1d(ksize, sigma)
+    k2 = (k1[:, None] * k1[None, :]).astype(f)
+    r = ksize // 2
+    pad = np.pad(depth[:, 0], ((0, 0), (r, r), (r, r)), mode="reflect")
+    blur = np.zeros((B, H, W), f)
+    for dy in range(ksize):
+        for dx in range(ksize):
+            blur += pad[:, dy:dy + H, dx:dx + W] * k2[dy, dx]
+    xyz = _f32(xyz_last).reshape(1, H, W, 3)
+    scale = blur[..., None] / (xyz[..., 2:] + f(1e-8))
+    g = (xyz * scale).astype(f)                                     # [B,H,W,3]
+    c = g[:, 1:-1, 1:-1]
+    up, down, left, right = g[:, :-2, 1:-1], g[:, 2:, 1:-1], g[:, 1:-1, :-2], g[:, 1:-1, 2:]
+    n = np.cross(up - c, left - c) + np.cross(left - c, down - c) + np.cross(down - c, right - c) + np.cross(right - c, up - c)
+    n = np.pad(n.astype(f), ((0, 0), (1, 1), (1, 1), (0, 0)), mode="edge")
+    n = n / (np.sqrt((n ** 2).sum(3, keepdims=True, dtype=f)) + f(1e-8))
+    ld = _f32(light_dir).reshape(B, 1, 1, 3)
+    diffuse = np.maximum(f(-1.0) * (n * ld).sum(3, dtype=f), f(0.0))
+    shading = (f(ka) + diffuse * f(kd)).astype(f)                  # [B,H,W]
+    out = rgba.copy()
+    out[:, :, :3] = np.clip(rgba[:, :, :3] * shading[:, None, None], f(0.0), f(1.0))
+    return out, shading
+
+
 def range_check(rgba) -> int:
     rgba = _f32(rgba)
     return int(_lib(False).gmpi_oracle_range_check(_ptr(rgba), rgba.size))

@@ -51,3 +51,30 @@ for S, B in ((256, 8), (512, 4), (1024, 4)):
     tf, tfb = timeit(fwd, 10), timeit(fwdbwd, 10)
     print(f"train-size {S}^2 x {D} planes, batch {B}: forward {tf:.3f} ms, forward+backward {tfb:.3f} ms "
           f"(backward ~{tfb - tf:.3f} ms, {B*S*S*D*16/ (tfb-tf)/1e6:.1f} G atomics/s)")
+
+# ---- shading augmentation (LightRenderer.render) on a 4 x 96 x 1024^2 volume, kernel by kernel ----
+import ctypes
+from ml_gmpi_amd import light
+from ml_gmpi_amd.hip_mpi import _DTYPES
+del vol
+for dt in (torch.float32, torch.bfloat16):
+    B, D, S = 4, 96, 1024
+    vol = torch.rand((B, D, 4, S, S), device=dev).to(dt)
+    L = ml_gmpi_amd.LightRenderer(sphere_center_z=1.0, sphere_r=1.0, ka_max=0.6, kd_max=0.9, n_grow_iters=1)
+    t_depth = timeit(lambda: light.compute_depth(vol[:, :, 3:], ds), 5)
+    d = light.compute_depth(vol[:, :, 3:], ds)
+    t_blur = timeit(lambda: L.blurrer_func(d), 5)
+    xyz_last = torch.stack((torch.linspace(-0.25, 0.25, S).expand(S, S), torch.linspace(-0.2, 0.2, S).view(S, 1).expand(S, S),
+                            torch.full((S, S), 1.12)), dim=-1).to(dev)
+    ld = torch.tensor([[0.1, -0.2, 0.97]] * B)
+    t_shade = timeit(lambda: L.shading(d, xyz_last, ld / ld.norm(dim=1, keepdim=True), 0.6, 0.9), 5)
+    sh = torch.rand((B, S, S), device=dev)
+    out = torch.empty((B, D, 4, S, S), device=dev)
+    st_ = (ctypes.c_int64 * 5)(*vol.stride())
+    t_apply = timeit(lambda: lib.gmpi_light_apply_launch(vol.data_ptr(), _DTYPES[vol.dtype], st_, sh.data_ptr(), out.data_ptr(), B, D, S, S,
+                                                        torch.cuda.current_stream().cuda_stream), 5)
+    es = vol.element_size()
+    gb_apply = B * D * S * S * (4 * es + 16) / 1e9
+    print(f"LightRenderer pieces {B}x{D}x{S}^2 {dt}: compute_depth {t_depth:.3f} ms, blur {t_blur:.3f} ms, shading {t_shade:.3f} ms, "
+          f"apply {t_apply:.3f} ms = {gb_apply / t_apply * 1e3:.0f} GB/s read+write ({gb_apply / t_apply / 8:.1%} of 8 TB/s)")
+    del vol, out
