@@ -198,8 +198,6 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     //      view needs 6 of the 7 (16-bit) / 10 of the 14 (fp32) item columns, so its lines fit in 1 instead of 2
     //      (16-bit) / 2 instead of 3 (fp32) passes -- the loader's VALU and request count shrink accordingly.
     int lcol = 0, lrowc = 0, perpass = kRowcPerPass, npass = kNL, dst_base = 0;
-    bool loader = false;
-    bool slot_ok[kNL];  // the LDS slot of item r exists (lines past the box but inside the buffer are simply zero-filled)
     uint32_t g_off[kNL];  // BYTE offset of item r inside a plane, relative to the box origin (32-bit voffset)
     auto set_loader_map = [&](int cols, int max_rows) {
         // (integer division runs on the VALU: readfirstlane tells the compiler the results are wave-uniform, so the
@@ -208,13 +206,12 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         npass = __builtin_amdgcn_readfirstlane((4 * max_rows + perpass - 1) / perpass);  // <= kNL: fewer columns -> more lines per pass
         lrowc = tid / cols;
         lcol = tid - lrowc * cols;
-        loader = lrowc < perpass;
         dst_base = lrowc * (kPitch / 4) + lcol * (TPI / 4);
+        if (lrowc >= perpass) lcol = 0x3fffffff;  // the last 512 % cols threads load nothing: every column test fails
 #pragma unroll
         for (int r = 0; r < kNL; ++r) {
             const int rowc = lrowc + r * perpass;
             g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) * static_cast<uint32_t>(sizeof(TexT));
-            slot_ok[r] = loader & (rowc < kMaxLines) & !(p.flags & (1u << 18));
         }
     };
 
@@ -294,12 +291,13 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // texture get the offset 0x80000000, which the hardware range check turns into zeros without touching
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
         // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
-        auto issue_loads = [&](auto np, int t, u32x4 (&L)[decltype(np)::value]) {
+        auto issue_loads = [&](auto np, int t, u32x4 (&L)[decltype(np)::value], bool (&in_box)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;  // passes of this chunk's loader map (compile-time: see run_staged)
             // Issued UNCONDITIONALLY, also for planes past the end of the chunk (all offsets out of range then: no
             // memory access): hipcc's waitcnt insertion only lets a load stay in flight across the next plane's
             // staged store ("vmcnt(NP)" instead of "vmcnt(0)") if every path issues the same number of loads.
             const bool live = (t < kn) & !(p.flags & (1u << 16));
+            const bool live_store = (t < kn) & !(p.flags & (1u << 18));
             const int4 rl = tabL[min(t, kn - 1)];
             // the descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a waterfall loop
             // (cdna_hip_programming.md T20): pass its inputs through readfirstlane.  Base = the box origin, so the
@@ -312,17 +310,23 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 reinterpret_cast<void*>((static_cast<uint64_t>(b_hi) << 32) | b_lo), 0, static_cast<int>(0x80000000u), 0x00020000);
             // item columns [clo, clo+ncol) and lines [llo, llo+nline) of the box lie inside the texture (one unsigned
             // compare each); everything else reads as zero ("zeros" padding) without touching memory
-            const int clo = (cols >> 8) & 0xff, ncol = (cols >> 16) & 0xff;
+            // (a plane that is not live gets empty ranges: the uniform flags stay on the scalar unit)
+            const int clo = (cols >> 8) & 0xff, ncol = live ? (cols >> 16) & 0xff : 0;
             const int llo = (lines >> 8) & 0xff, nline = (lines >> 16) & 0xff;
-            const bool col_ok = loader & live & (static_cast<unsigned>(lcol - clo) < static_cast<unsigned>(ncol));
+            const bool col_ok = static_cast<unsigned>(lcol - clo) < static_cast<unsigned>(ncol);
+            // which LDS slots the staged store of this plane has to write: the box itself (texels of it that lie
+            // outside the texture are written as the zeros the loads return); lanes outside the box stay idle --
+            // LDS write time goes with the number of active lanes (tools/ubench/lds_read_rate.hip)
+            const bool col_in_box = lcol < (live_store ? (cols & 0xff) : 0);
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
+                in_box[r] = col_in_box & (lrowc + r * perpass < (lines & 0xff));
                 const bool ok = col_ok & (static_cast<unsigned>(lrowc + (r * perpass - llo)) < static_cast<unsigned>(nline));
                 const uint32_t off = ok ? g_off[r] : 0x80000000u;  // == num_records: rejected; off+15 cannot wrap
                 L[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
             }
         };
-        auto store_box = [&](auto np, float* tile, u32x4 (&L)[decltype(np)::value]) {
+        auto store_box = [&](auto np, float* tile, u32x4 (&L)[decltype(np)::value], const bool (&in_box)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;
             // LDS slot of item r: line (lrowc + perpass*r), floats [TPI*lcol, TPI*lcol + TPI)
             float4* dst = reinterpret_cast<float4*>(tile) + dst_base;
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
 #pragma unroll
                 for (int h = 0; h < TPI / 4; ++h) {
                     mx = max(max(mx, __float_as_uint(q[h].x)), max(max(__float_as_uint(q[h].y), __float_as_uint(q[h].z)), __float_as_uint(q[h].w)));
-                    if (slot_ok[r]) dst[r * pass_stride + h] = q[h];
+                    if (in_box[r]) dst[r * pass_stride + h] = q[h];
                 }
             }
             // [0,1] test on bit patterns: non-negative floats order like unsigned ints, so v in [0,1] <=> bits <=
@@ -353,7 +357,8 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         };
 
         auto composite = [&](int t, const float* __restrict__ tile, bool mine) {
-            if (!mine | ((p.flags & (1u << 17)) != 0)) return;
+            if (t >= kn || (p.flags & (1u << 17))) return;  // workgroup-uniform: padding plane / ablation
+            if (!mine) return;
             const float4 rf = tabF[t];
             const int4 rg = tabG[t];
             float ix, iy, s;
@@ -399,18 +404,19 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             constexpr int NP = decltype(np)::value;
             constexpr int PFX = NP * PF <= kMaxStagedItems ? PF : (NP * 2 <= kMaxStagedItems ? 2 : 1);  // planes in flight
             u32x4 L[PFX][NP];  // staging registers: the loads run PFX planes ahead of the compositor
+            bool in_box[PFX][NP];  // ... and the lanes that will store them
     #pragma unroll
-            for (int u = 0; u < PFX; ++u) issue_loads(np, u, L[u]);
+            for (int u = 0; u < PFX; ++u) issue_loads(np, u, L[u], in_box[u]);
             // every stage runs for every t (a chunk is padded to a multiple of PFX planes: the padding planes load
             // and stage nothing and are not composited), so the memory operations are the same on every path
             for (int t = 0; t < kn; t += PFX) {
     #pragma unroll
                 for (int u = 0; u < PFX; ++u) {
                     float* tile = tile0 + ((t + u) & 1) * kCapFloats;
-                    store_box(np, tile, L[u]);
+                    store_box(np, tile, L[u], in_box[u]);
                     __syncthreads();  // box t+u visible; everybody is done reading box t+u-1 (the other buffer)
-                    issue_loads(np, t + u + PFX, L[u]);  // in flight while the PFX planes before it are composited
-                    composite(t + u, tile, mine & (t + u < kn));
+                    issue_loads(np, t + u + PFX, L[u], in_box[u]);  // in flight while the PFX planes before it are composited
+                    composite(t + u, tile, mine);
                 }
             }
         };
