@@ -48,6 +48,24 @@ def algorithmic_bytes(n_views, D, S, s_in, want_T):
     return n_views * D * 4 * S * S * s_in + n_views * S * S * 12 + n_views * S * S * 4 * (4 + (1 if want_T else 0))
 
 
+def footprint_bytes(ray, eye, dhw, S, s_in, want_T):
+    """Conservative companion of the algorithmic bytes: only the texel bounding box each view touches on
+    each plane (from the 4 image-corner rays, align_corners=True grid), plus the per-pixel bytes."""
+    n = ray.shape[0]
+    r = ray.double().cpu()[:, :, [0, 0, -1, -1], [0, -1, 0, -1]]          # [N,3,4] corner rays
+    e = eye.double().cpu()
+    d = dhw.double().cpu()[0]                                               # [D,3] (same planes for every MPI here)
+    sc = (d[None, :, 0, None] - e[:, None, 2, None]) / r[:, None, 2, :]      # [N,D,4]
+    x = e[:, None, 0, None] + r[:, None, 0, :] * sc
+    y = e[:, None, 1, None] + r[:, None, 1, :] * sc
+    ix = (2 * x / d[None, :, 2, None] + 1) * (S - 1) / 2
+    iy = (2 * y / d[None, :, 1, None] + 1) * (S - 1) / 2
+    w = (ix.max(-1).values.floor() + 1).clamp(0, S - 1) - ix.min(-1).values.floor().clamp(0, S - 1) + 1
+    h = (iy.max(-1).values.floor() + 1).clamp(0, S - 1) - iy.min(-1).values.floor().clamp(0, S - 1) + 1
+    texels = float((w.clamp(min=0) * h.clamp(min=0)).sum())
+    return int(texels * 4 * s_in + n * S * S * 12 + n * S * S * 4 * (4 + (1 if want_T else 0)))
+
+
 def cpu_baseline(preset, S, D, dtype, budget_s=20.0):
     """Oracle (OpenMP) on ONE view of the workload shape, repeated until ~budget_s of CPU wall time."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -195,6 +213,7 @@ def main():
         s_in = 2 if dtype == "bf16" else 4
         abytes = algorithmic_bytes(n_views, D, S, s_in, want_T)
         achieved = abytes / (kern_ms * 1e-3) / 1e9
+        fbytes = footprint_bytes(ray, eye, dhw, S, s_in, want_T)
         traffic = None
         prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes per launch, if measured
         if os.path.isfile(prof):
@@ -212,7 +231,9 @@ def main():
             "views_per_s": round(n_views * world * a.steps / elapsed, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": abytes},
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": abytes,
+                         # conservative companion: only the texel boxes the views actually touch
+                         "footprint_bytes_per_launch": fbytes, "frac_footprint": round(fbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "e2e_render_ms": round(e2e_ms, 3), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
         }
         if not a.no_cpu_baseline and world == 1:
