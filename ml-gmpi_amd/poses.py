@@ -103,8 +103,16 @@ def look_at_centre(pos: torch.Tensor) -> torch.Tensor:
     return trans @ rot
 
 
+_FRAME_CACHE = {}
+
+
 def sphere_to_mpi_frame(sphere_center: np.ndarray) -> np.ndarray:
-    """4x4 float64: sphere-frame coordinates -> MPI-frame coordinates (rotate axes, then move to the centre)."""
+    """4x4 float64: sphere-frame coordinates -> MPI-frame coordinates (rotate axes, then move to the centre).
+    Constant per renderer, so the matrix is cached per centre (two scipy Rotation objects per call otherwise)."""
+    key = tuple(float(v) for v in np.asarray(sphere_center, dtype=np.float64).reshape(-1))
+    hit = _FRAME_CACHE.get(key)
+    if hit is not None:
+        return hit.copy()
     turn_z = np.eye(4)
     turn_z[:3, :3] = Rotation.from_euler("Z", -90, degrees=True).as_matrix()  # -> +X right, +Y forward, +Z up
     turn_x = np.eye(4)
@@ -112,7 +120,10 @@ def sphere_to_mpi_frame(sphere_center: np.ndarray) -> np.ndarray:
     rot = np.matmul(turn_x, turn_z)
     shift = np.eye(4)
     shift[:3, 3] = np.asarray(sphere_center).reshape(-1)
-    return np.matmul(shift, rot)
+    out = np.matmul(shift, rot)
+    if len(_FRAME_CACHE) < 64:
+        _FRAME_CACHE[key] = out.copy()
+    return out
 
 
 def gen_sphere_path(n_cams: int, sphere_center: np.ndarray, sphere_r: Optional[float], yaw_mean=0.0,
