@@ -192,6 +192,23 @@ int gmpi_light_shading_launch(const float *depth_blurred, const float *xyz_last,
 int gmpi_light_apply_launch(const void *rgba, int32_t rgba_dtype, const int64_t *rgba_stride, const float *shading, float *out,
                             int32_t B, int32_t D, int32_t H, int32_t W, void *stream);
 
+/*
+ * Backward of the two volume-sized ops of the augmentation (the reference runs it inside the G-step with autograd,
+ * train.py:535-541):
+ *  - gmpi_light_apply_backward_launch: grad_out [B,D,4,H,W] fp32 contiguous -> grad_rgba [B,D,4,H,W] fp32 contiguous
+ *    (rgb: grad*shading where 0 <= rgb*shading <= 1, alpha: passed through) and grad_shading [B,H,W].
+ *  - gmpi_alpha_depth_backward_launch: gradient of gmpi_alpha_depth_launch w.r.t. alpha, ADDED to grad_alpha (an fp32
+ *    [B,D,1,H,W] view with the given element strides, e.g. channel 3 of grad_rgba).  `transmittance` is the forward's
+ *    transmittance_out or NULL.
+ */
+int gmpi_light_apply_backward_launch(const void *rgba, int32_t rgba_dtype, const int64_t *rgba_stride, const float *shading,
+                                     const float *grad_out, float *grad_rgba, float *grad_shading, int32_t B, int32_t D,
+                                     int32_t H, int32_t W, void *stream);
+int gmpi_alpha_depth_backward_launch(const void *alpha, int32_t alpha_dtype, int64_t stride_b, int64_t stride_d,
+                                     int64_t stride_row, const float *plane_ds, const float *transmittance,
+                                     const float *grad_depth, float *grad_alpha, int64_t gstride_b, int64_t gstride_d,
+                                     int64_t gstride_row, int32_t B, int32_t D, int32_t H, int32_t W, void *stream);
+
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
  * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height.  Unknown -> -1.      */
 int gmpi_query(int32_t what);

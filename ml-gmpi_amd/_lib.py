@@ -31,6 +31,8 @@ EXPORTS = (
     "gmpi_light_blur_launch",
     "gmpi_light_shading_launch",
     "gmpi_light_apply_launch",
+    "gmpi_light_apply_backward_launch",
+    "gmpi_alpha_depth_backward_launch",
     "gmpi_query",
     "gmpi_version_string",
 )
@@ -124,6 +126,13 @@ def load_library():
     lib.gmpi_light_apply_launch.restype = ctypes.c_int
     lib.gmpi_light_apply_launch.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), vp, vp, ctypes.c_int32,
                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    lib.gmpi_light_apply_backward_launch.restype = ctypes.c_int
+    lib.gmpi_light_apply_backward_launch.argtypes = [vp, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64), vp, vp, vp, vp,
+                                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    lib.gmpi_alpha_depth_backward_launch.restype = ctypes.c_int
+    lib.gmpi_alpha_depth_backward_launch.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, vp,
+                                                     vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                                     ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     lib.gmpi_query.restype = ctypes.c_int
     lib.gmpi_query.argtypes = [ctypes.c_int32]
     lib.gmpi_version_string.restype = ctypes.c_char_p

@@ -107,6 +107,77 @@ static void launch_light_apply(const void* rgba, const int64_t* st, const float*
     else hipLaunchKernelGGL((light_apply_kernel<T, 1>), dim3((W + 255) / 256, H, B * D), dim3(256), 0, stream, src, st[0], st[1], st[2], st[3], shading, out, D, H, W);
 }
 
+// ---- backward of the augmentation (the reference applies it inside the G-step, train.py:535-541, 703-709) -------------
+// Only the two volume-sized ops need kernels; the B*H*W middle (blur, point cloud, normals, Lambert) is differentiated by
+// torch autograd in light.py.
+//
+// (1) out = clip(rgb * s, 0, 1) | alpha:   g_rgb = g_out * s * [0 < rgb*s < 1],  g_alpha = g_out_alpha (more is added by (2)),
+//     g_s[b,y,x] = sum_{k,c} g_out * rgb * [0 < rgb*s < 1].  One pixel column per thread, planes in a loop (coalesced in x).
+//     torch.clip passes the gradient at the bounds themselves (min <= x <= max), so the mask is closed.
+template <typename T>
+__global__ __launch_bounds__(256) void light_apply_backward_kernel(const T* __restrict__ rgba, int64_t sb, int64_t sd, int64_t sc,
+                                                                   int64_t sr, const float* __restrict__ shading,
+                                                                   const float* __restrict__ g_out, float* __restrict__ g_rgba,
+                                                                   float* __restrict__ g_shading, int D, int H, int W) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    const int64_t plane = static_cast<int64_t>(H) * W, pix = static_cast<int64_t>(y) * W + x;
+    const float s = shading[b * plane + pix];
+    float gs = 0.0f;
+    for (int k = 0; k < D; ++k) {
+        const T* __restrict__ src = rgba + b * sb + k * sd + static_cast<int64_t>(y) * sr + x;
+        const int64_t o = (static_cast<int64_t>(b) * D + k) * 4 * plane + pix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = to_f32(src[c * sc]), g = g_out[o + c * plane];
+            const float t = v * s;
+            const bool pass = t >= 0.0f && t <= 1.0f;
+            g_rgba[o + c * plane] = pass ? g * s : 0.0f;
+            gs += pass ? g * v : 0.0f;
+        }
+        g_rgba[o + 3 * plane] = g_out[o + 3 * plane];
+    }
+    g_shading[b * plane + pix] = gs;
+}
+
+// (2) depth = sum_k a_k T_k d_k (compute_depth): dL/da_k = g (T_k d_k - S_k / om_k), S_k = sum_{j>k} a_j T_j d_j, back to
+//     front from the forward's final transmittance (same scheme as render_backward.hip: no cancellation behind opaque
+//     planes; T carried as mantissa x 2^exponent).  ADDS into g_alpha (the alpha channel of the volume gradient).
+template <typename T>
+__global__ __launch_bounds__(256) void alpha_depth_backward_kernel(const T* __restrict__ alpha, int64_t sb, int64_t sd, int64_t sr,
+                                                                   const float* __restrict__ ds, const float* __restrict__ t_final,
+                                                                   const float* __restrict__ g_depth, float* __restrict__ g_alpha,
+                                                                   int64_t gb, int64_t gd, int64_t gr, int D, int H, int W) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    const T* __restrict__ a = alpha + b * sb + static_cast<int64_t>(y) * sr + x;
+    float* __restrict__ ga = g_alpha + b * gb + static_cast<int64_t>(y) * gr + x;
+    const int64_t o = (static_cast<int64_t>(b) * H + y) * W + x;
+    const float g = g_depth[o];
+    float tm = t_final ? t_final[o] : 0.0f;
+    int te = 0;
+    if (!(tm >= 1e-30f)) {  // missing or underflowed: rebuild front to back in the extended representation
+        tm = 1.0f;
+        for (int k = 0; k < D; ++k) {
+            tm *= (1.0f - to_f32(a[k * sd])) + 1e-10f;
+            te += __builtin_amdgcn_frexp_expf(tm);
+            tm = __builtin_amdgcn_frexp_mantf(tm);
+        }
+    }
+    float S = 0.0f;
+    for (int k = D - 1; k >= 0; --k) {
+        const float al = to_f32(a[k * sd]);
+        const float om = (1.0f - al) + 1e-10f;
+        tm = tm / om;
+        te += __builtin_amdgcn_frexp_expf(tm);
+        tm = __builtin_amdgcn_frexp_mantf(tm);
+        const float Tk = __builtin_amdgcn_ldexpf(tm, te);
+        const float q = g * ds[k];
+        ga[k * gd] += Tk * q - S / om;
+        S += al * Tk * q;
+    }
+}
+
 static int rc_of(hipError_t e) { return e == hipSuccess ? GMPI_OK : GMPI_E_LAUNCH - static_cast<int>(e); }
 
 }  // namespace gmpi
@@ -147,6 +218,40 @@ int gmpi_light_apply_launch(const void* rgba, int32_t rgba_dtype, const int64_t*
     if (rgba_dtype == GMPI_DTYPE_F32) launch_light_apply<float>(rgba, rgba_stride, shading, out, B, D, H, W, st);
     else if (rgba_dtype == GMPI_DTYPE_BF16) launch_light_apply<bf16_t>(rgba, rgba_stride, shading, out, B, D, H, W, st);
     else launch_light_apply<f16_t>(rgba, rgba_stride, shading, out, B, D, H, W, st);
+    return rc_of(hipGetLastError());
+}
+
+int gmpi_light_apply_backward_launch(const void* rgba, int32_t rgba_dtype, const int64_t* rgba_stride, const float* shading,
+                                     const float* grad_out, float* grad_rgba, float* grad_shading, int32_t B, int32_t D, int32_t H,
+                                     int32_t W, void* stream) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0) return GMPI_E_SHAPE;
+    if (B == 0) return GMPI_OK;
+    if (!rgba || !rgba_stride || !shading || !grad_out || !grad_rgba || !grad_shading) return GMPI_E_NULL;
+    if (rgba_dtype < GMPI_DTYPE_F32 || rgba_dtype > GMPI_DTYPE_F16) return GMPI_E_DTYPE;
+    if (rgba_stride[4] != 1 || rgba_stride[3] < W || rgba_stride[2] <= 0 || rgba_stride[1] <= 0 || rgba_stride[0] < 0) return GMPI_E_STRIDE;
+    const dim3 grid((W + 255) / 256, H, B), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t sb = rgba_stride[0], sd = rgba_stride[1], sc = rgba_stride[2], sr = rgba_stride[3];
+    if (rgba_dtype == GMPI_DTYPE_F32) hipLaunchKernelGGL(light_apply_backward_kernel<float>, grid, block, 0, st, static_cast<const float*>(rgba), sb, sd, sc, sr, shading, grad_out, grad_rgba, grad_shading, D, H, W);
+    else if (rgba_dtype == GMPI_DTYPE_BF16) hipLaunchKernelGGL(light_apply_backward_kernel<bf16_t>, grid, block, 0, st, static_cast<const bf16_t*>(rgba), sb, sd, sc, sr, shading, grad_out, grad_rgba, grad_shading, D, H, W);
+    else hipLaunchKernelGGL(light_apply_backward_kernel<f16_t>, grid, block, 0, st, static_cast<const f16_t*>(rgba), sb, sd, sc, sr, shading, grad_out, grad_rgba, grad_shading, D, H, W);
+    return rc_of(hipGetLastError());
+}
+
+int gmpi_alpha_depth_backward_launch(const void* alpha, int32_t alpha_dtype, int64_t stride_b, int64_t stride_d, int64_t stride_row,
+                                     const float* plane_ds, const float* transmittance, const float* grad_depth, float* grad_alpha,
+                                     int64_t gstride_b, int64_t gstride_d, int64_t gstride_row, int32_t B, int32_t D, int32_t H,
+                                     int32_t W, void* stream) {
+    if (B < 0 || D <= 0 || H <= 0 || W <= 0) return GMPI_E_SHAPE;
+    if (B == 0) return GMPI_OK;
+    if (!alpha || !plane_ds || !grad_depth || !grad_alpha) return GMPI_E_NULL;
+    if (alpha_dtype < GMPI_DTYPE_F32 || alpha_dtype > GMPI_DTYPE_F16) return GMPI_E_DTYPE;
+    if (stride_b < 0 || stride_d <= 0 || stride_row < W || gstride_b <= 0 || gstride_d <= 0 || gstride_row < W) return GMPI_E_STRIDE;
+    const dim3 grid((W + 255) / 256, H, B), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (alpha_dtype == GMPI_DTYPE_F32) hipLaunchKernelGGL(alpha_depth_backward_kernel<float>, grid, block, 0, st, static_cast<const float*>(alpha), stride_b, stride_d, stride_row, plane_ds, transmittance, grad_depth, grad_alpha, gstride_b, gstride_d, gstride_row, D, H, W);
+    else if (alpha_dtype == GMPI_DTYPE_BF16) hipLaunchKernelGGL(alpha_depth_backward_kernel<bf16_t>, grid, block, 0, st, static_cast<const bf16_t*>(alpha), stride_b, stride_d, stride_row, plane_ds, transmittance, grad_depth, grad_alpha, gstride_b, gstride_d, gstride_row, D, H, W);
+    else hipLaunchKernelGGL(alpha_depth_backward_kernel<f16_t>, grid, block, 0, st, static_cast<const f16_t*>(alpha), stride_b, stride_d, stride_row, plane_ds, transmittance, grad_depth, grad_alpha, gstride_b, gstride_d, gstride_row, D, H, W);
     return rc_of(hipGetLastError());
 }
 

@@ -6,13 +6,15 @@ streaming HIP kernel and the running transmittance lives in a register -- the re
 warp.  `LightRenderer.render` chains it with three more kernels (csrc/light_kernels.hip): Gaussian blur of the depth,
 point cloud -> normals -> Lambert shading per texel, and `clip(rgb * shading, 0, 1)` over the volume.
 
-Forward only: the reference uses the augmentation inside the G-step with autograd; here a volume that requires grad
-is refused (NotImplementedError) rather than silently detached.
+The reference applies the augmentation inside the G-step (train.py:535-541): when the volume requires grad the same
+kernels run under a `torch.autograd.Function` whose backward uses two more streaming kernels for the volume-sized ops
+(clip(rgb*shading) and the alpha compositing of the depth) and torch autograd for the B*H*W middle (blur, normals, Lambert).
 """
 import ctypes
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import _lib, poses
 from .hip_mpi import _DTYPES
@@ -52,6 +54,70 @@ def gaussian_kernel1d(ksize: int, sigma: float) -> torch.Tensor:
     x = torch.linspace(-lim, lim, steps=ksize)
     pdf = torch.exp(-0.5 * (x / sigma).pow(2))
     return pdf / pdf.sum()
+
+
+def _blur_torch(depth: torch.Tensor, k1d: torch.Tensor) -> torch.Tensor:
+    """torch restatement of gaussian_blur_kernel ([B,1,H,W]); only used to differentiate the middle of the pipeline."""
+    r = k1d.numel() // 2
+    k2d = torch.outer(k1d, k1d).to(depth)[None, None]
+    return F.conv2d(F.pad(depth, (r, r, r, r), mode="reflect"), k2d)
+
+
+def _shading_torch(depth_blurred: torch.Tensor, xyz_last: torch.Tensor, light_dir: torch.Tensor, ka: float, kd: float) -> torch.Tensor:
+    """torch restatement of light_shading_kernel (compute_pcl :102-120, get_normal :57-80, Lambert :163-190) -> [B,H,W]."""
+    xyz = xyz_last.to(depth_blurred)[None]
+    g = xyz * (depth_blurred[:, 0].unsqueeze(-1) / (xyz[..., 2:] + EPS))
+    c = g[:, 1:-1, 1:-1]
+    up, down, left, right = g[:, :-2, 1:-1], g[:, 2:, 1:-1], g[:, 1:-1, :-2], g[:, 1:-1, 2:]
+    n = (torch.cross(up - c, left - c, dim=3) + torch.cross(left - c, down - c, dim=3)
+         + torch.cross(down - c, right - c, dim=3) + torch.cross(right - c, up - c, dim=3))
+    n = F.pad(n.permute(0, 3, 1, 2), (1, 1, 1, 1), mode="replicate").permute(0, 2, 3, 1)
+    n = n / (((n ** 2).sum(3, keepdim=True)) ** 0.5 + EPS)
+    diffuse = (-1 * (n * light_dir.to(depth_blurred).view(-1, 1, 1, 3)).sum(3)).clamp(min=0)
+    return ka + diffuse * kd
+
+
+class _LightFunction(torch.autograd.Function):
+    """LightRenderer.render as one autograd node: forward = the four kernels, backward = apply-backward kernel, torch
+    autograd through the B*H*W middle, alpha-depth-backward kernel (adds into the alpha channel of the gradient)."""
+
+    @staticmethod
+    def forward(ctx, vol, renderer, plane_ds, xyz_last, light_dir, ka, kd):
+        out, depth, T, shading = renderer._forward_kernels(vol.detach(), plane_ds, xyz_last, light_dir, ka, kd)
+        ctx.save_for_backward(vol.detach(), depth, T, shading)
+        ctx.misc = (renderer._k1d, plane_ds, xyz_last, light_dir, ka, kd, vol.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.load_library()
+        vol, depth, T, shading = ctx.saved_tensors
+        k1d, plane_ds, xyz_last, light_dir, ka, kd, in_dtype = ctx.misc
+        dev = vol.device
+        B, D, _, H, W = vol.shape
+        g_out = g_out.to(torch.float32).contiguous()
+        g_rgba = torch.empty((B, D, 4, H, W), dtype=torch.float32, device=dev)
+        g_shading = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        strides = (ctypes.c_int64 * 5)(*vol.stride())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(lib.gmpi_light_apply_backward_launch(vol.data_ptr(), _DTYPES[vol.dtype], strides, shading.data_ptr(),
+                                                            g_out.data_ptr(), g_rgba.data_ptr(), g_shading.data_ptr(), B, D, H, W,
+                                                            stream), "gmpi_light_apply_backward_launch")
+        with torch.enable_grad():
+            d = depth.detach().requires_grad_(True)
+            s = _shading_torch(_blur_torch(d, k1d.to(dev)), xyz_last.to(dev), light_dir.to(dev), ka, kd)
+            (g_depth,) = torch.autograd.grad(s, d, g_shading)
+        g_depth = g_depth.contiguous()
+        alpha = vol[:, :, 3:]
+        ds = plane_ds.reshape(-1).to(dev, torch.float32).contiguous()
+        plane = H * W
+        with torch.cuda.device(dev):
+            _lib.check(lib.gmpi_alpha_depth_backward_launch(
+                alpha.data_ptr(), _DTYPES[vol.dtype], alpha.stride(0), alpha.stride(1), alpha.stride(3), ds.data_ptr(),
+                T.data_ptr(), g_depth.data_ptr(), g_rgba.data_ptr() + 3 * plane * 4, D * 4 * plane, 4 * plane, W, B, D, H, W,
+                stream), "gmpi_alpha_depth_backward_launch")
+        return g_rgba.to(in_dtype), None, None, None, None, None, None
 
 
 class LightRenderer:
@@ -103,37 +169,45 @@ class LightRenderer:
         return out
 
     # -- light_renderer.py:122-199 ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _forward_kernels(self, vol, plane_ds, xyz_last, light_direction, ka, kd):
+        lib = _lib.load_library()
+        dev = vol.device
+        B, D, _, H, W = vol.shape
+        depth, T = compute_depth(vol[:, :, 3:], plane_ds, want_transmittance=True)
+        blurred = self.blurrer_func(depth)
+        shading = self.shading(blurred, xyz_last, light_direction, ka, kd)
+        out = torch.empty((B, D, 4, H, W), dtype=torch.float32, device=dev)
+        strides = (ctypes.c_int64 * 5)(*vol.stride())
+        with torch.cuda.device(dev):
+            _lib.check(lib.gmpi_light_apply_launch(vol.data_ptr(), _DTYPES[vol.dtype], strides, shading.data_ptr(),
+                                                   out.data_ptr(), B, D, H, W, torch.cuda.current_stream(dev).cuda_stream),
+                       "gmpi_light_apply_launch")
+        return out, depth, T, shading
+
     def render(self, batch_mpi: torch.Tensor, mpi_plane_dhws: torch.Tensor, mpi_tex_pix_xyz: torch.Tensor) -> torch.Tensor:
-        """batch_mpi [B,D,4,H,W], mpi_plane_dhws [D,3], mpi_tex_pix_xyz [D,H,W,>=3] -> shaded MPI [B,D,4,H,W] float32."""
+        """batch_mpi [B,D,4,H,W], mpi_plane_dhws [D,3], mpi_tex_pix_xyz [D,H,W,>=3] -> shaded MPI [B,D,4,H,W] float32
+        (differentiable w.r.t. batch_mpi)."""
         if not batch_mpi.is_cuda:
             raise _lib.GmpiError("LightRenderer.render needs tensors on a ROCm device (no CPU path)")
-        if torch.is_grad_enabled() and batch_mpi.requires_grad:
-            raise NotImplementedError("the shading augmentation is forward-only here (see ml_gmpi_amd/light.py)")
-        lib = _lib.load_library()
         self.step += 1
         dev = batch_mpi.device
         vol = batch_mpi if batch_mpi.dtype in _DTYPES else batch_mpi.float()
         if vol.stride(4) != 1 or any(s < 0 for s in vol.stride()):
             vol = vol.contiguous()
-        B, D, _, H, W = vol.shape
-        with torch.no_grad():
-            depth = compute_depth(vol[:, :, 3:], mpi_plane_dhws[:, :1].to(dev))
-            depth = self.blurrer_func(depth)
-            # light position on the sphere (consumes the torch RNG exactly as the reference's gen_sphere_path call)
-            c2w, _, _ = poses.gen_sphere_path(n_cams=B, sphere_center=self.sphere_center, sphere_r=self.sphere_r,
-                                              yaw_mean=self.l_h_mean, yaw_std=self.l_h_std, pitch_mean=self.l_v_mean,
-                                              pitch_std=self.l_v_std, n_truncated_stds=2, flag_rnd=True,
-                                              sample_method="truncated_gaussian", given_yaws=None, given_pitches=None)
-            light_pos = c2w[:, :3, 3]
-            light_pos = light_pos if isinstance(light_pos, torch.Tensor) else torch.FloatTensor(light_pos)
-            light_direction = poses._unit(self.sphere_center.reshape(1, 3) - light_pos)  # towards the sphere centre
-            cur_ratio = min(1.0, self.step / self.n_grow_iters)
-            self.cur_ka, self.cur_kd = cur_ratio * self.ka_max, cur_ratio * self.kd_max
-            shading = self.shading(depth, mpi_tex_pix_xyz[-1, :, :, :3], light_direction, self.cur_ka, self.cur_kd)
-            out = torch.empty((B, D, 4, H, W), dtype=torch.float32, device=dev)
-            strides = (ctypes.c_int64 * 5)(*vol.stride())
-            with torch.cuda.device(dev):
-                _lib.check(lib.gmpi_light_apply_launch(vol.data_ptr(), _DTYPES[vol.dtype], strides, shading.data_ptr(),
-                                                       out.data_ptr(), B, D, H, W, torch.cuda.current_stream(dev).cuda_stream),
-                           "gmpi_light_apply_launch")
-        return out
+        B = vol.shape[0]
+        # light position on the sphere (consumes the torch RNG exactly as the reference's gen_sphere_path call)
+        c2w, _, _ = poses.gen_sphere_path(n_cams=B, sphere_center=self.sphere_center, sphere_r=self.sphere_r,
+                                          yaw_mean=self.l_h_mean, yaw_std=self.l_h_std, pitch_mean=self.l_v_mean,
+                                          pitch_std=self.l_v_std, n_truncated_stds=2, flag_rnd=True,
+                                          sample_method="truncated_gaussian", given_yaws=None, given_pitches=None)
+        light_pos = c2w[:, :3, 3]
+        light_pos = light_pos if isinstance(light_pos, torch.Tensor) else torch.FloatTensor(light_pos)
+        light_direction = poses._unit(self.sphere_center.reshape(1, 3) - light_pos)  # towards the sphere centre
+        cur_ratio = min(1.0, self.step / self.n_grow_iters)
+        self.cur_ka, self.cur_kd = cur_ratio * self.ka_max, cur_ratio * self.kd_max
+        plane_ds = mpi_plane_dhws[:, :1].detach().to(dev)
+        xyz_last = mpi_tex_pix_xyz[-1, :, :, :3].detach()
+        if torch.is_grad_enabled() and vol.requires_grad:
+            return _LightFunction.apply(vol, self, plane_ds, xyz_last, light_direction, self.cur_ka, self.cur_kd)
+        return self._forward_kernels(vol, plane_ds, xyz_last, light_direction, self.cur_ka, self.cur_kd)[0]

@@ -56,15 +56,53 @@ def test_hip_light_render_matches_reference_and_oracle(name, kw, steps, dtype):
 
 
 @pytest.mark.gpu
-def test_hip_light_render_refuses_autograd_and_handles_strided_volume():
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hip_light_render_backward_matches_autograd(dtype):
+    """G-step use (train.py:535-541): gradient w.r.t. the MPI through clip(rgb*shading), the shading's dependence on
+    alpha (normals of the composited depth) and the alpha pass-through, against torch autograd in float64."""
+    import ml_gmpi_amd
+    from ml_gmpi_amd import poses
+    from _torch_ref import torch_light_render
+    fx = load_npz("light_render.npz")
+    dev = torch.device("cuda:0")
+    base = torch.from_numpy(fx["rgba"]).to(dtype)
+    base[:, 2, :3, :, :8] = 0.0                       # rgb*s == 0: torch.clip passes the gradient at the bound
+    vol = base.to(dev).requires_grad_(True)
+    dhw, xyz = torch.from_numpy(fx["dhw"]), torch.from_numpy(fx["xyz"])
+    L = ml_gmpi_amd.LightRenderer(sphere_center_z=1.0, sphere_r=1.0, ka_max=1.3, kd_max=0.9, n_grow_iters=1)
+    L.step = 4                                        # ratio 1: ka 1.3 (some rgb*s clip at 1), kd 0.9
+    torch.manual_seed(11)
+    out = L.render(vol, dhw, xyz.to(dev))
+    assert out.requires_grad
+    g = torch.from_numpy(np.random.default_rng(3).standard_normal(out.shape).astype(np.float32))
+    (out * g.to(dev)).sum().backward()
+    got = vol.grad.float().cpu().numpy()
+    # reference: same light (same RNG draw), float64 autograd
+    torch.manual_seed(11)
+    c2w, _, _ = poses.gen_sphere_path(n_cams=2, sphere_center=L.sphere_center, sphere_r=1.0, yaw_mean=L.l_h_mean, yaw_std=L.l_h_std,
+                                      pitch_mean=L.l_v_mean, pitch_std=L.l_v_std, n_truncated_stds=2, flag_rnd=True,
+                                      sample_method="truncated_gaussian")
+    ld = poses._unit(L.sphere_center.reshape(1, 3) - torch.FloatTensor(c2w[:, :3, 3])).double()
+    ref_in = base.double().requires_grad_(True)
+    ref = torch_light_render(ref_in, dhw[:, 0].double(), xyz[-1].double(), ld, L.cur_ka, L.cur_kd, L._k1d.double())
+    (ref * g.double()).sum().backward()
+    want = ref_in.grad.numpy()
+    assert np.abs(out.detach().cpu().numpy() - ref.detach().numpy()).max() <= 1e-5
+    scale = np.abs(want).max()
+    err = np.abs(got - want).max()
+    assert err <= (2e-4 if dtype == torch.float32 else 1e-2) * scale, (err, scale)   # bf16: the returned gradient is rounded to bf16
+    # the alpha gradient really contains the shading path (not only the pass-through of g)
+    assert np.abs(want[:, :, 3] - g.numpy()[:, :, 3]).max() > 1e-3 * scale
+
+
+@pytest.mark.gpu
+def test_hip_light_render_handles_strided_volume():
     import ml_gmpi_amd
     fx = load_npz("light_render.npz")
     dev = torch.device("cuda:0")
     L = ml_gmpi_amd.LightRenderer(sphere_center_z=1.0, sphere_r=1.0, ka_max=0.6, kd_max=0.9, n_grow_iters=1)
     dhw, xyz = torch.from_numpy(fx["dhw"]), torch.from_numpy(fx["xyz"]).to(dev)
     vol = torch.from_numpy(fx["rgba"]).to(dev)
-    with pytest.raises(NotImplementedError):
-        L.render(vol.clone().requires_grad_(True), dhw, xyz)
     padded = torch.zeros((2, 6, 4, 32, 40), device=dev)
     padded[..., :32] = vol
     torch.manual_seed(5)
