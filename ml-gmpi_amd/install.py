@@ -13,8 +13,9 @@ import sys
 _SAVED = {}
 
 
-def install(patch_mpi: bool = True, patch_renderer: bool = True) -> None:
+def install(patch_mpi: bool = True, patch_renderer: bool = True, patch_light: bool = True) -> None:
     from .hip_mpi import MPI
+    from .light import LightRenderer
     from .renderer import MPIRenderer
 
     core_mpi = importlib.import_module("gmpi.core.mpi")
@@ -27,6 +28,16 @@ def install(patch_mpi: bool = True, patch_renderer: bool = True) -> None:
     if patch_renderer:
         _SAVED.setdefault(("gmpi.core.mpi_renderer", "MPIRenderer"), core_renderer.MPIRenderer)
         core_renderer.MPIRenderer = MPIRenderer
+    if patch_light:
+        # train.py:23 `from gmpi.core.light_renderer import LightRenderer`.  The reference module imports torchvision at
+        # import time; where that is unavailable the module cannot be imported and there is nothing to patch.
+        try:
+            core_light = importlib.import_module("gmpi.core.light_renderer")
+        except ImportError:
+            core_light = None
+        if core_light is not None:
+            _SAVED.setdefault(("gmpi.core.light_renderer", "LightRenderer"), core_light.LightRenderer)
+            core_light.LightRenderer = LightRenderer
 
 
 def uninstall() -> None:

@@ -24,6 +24,9 @@ def test_install_patches_the_reference_modules_and_uninstall_restores():
         # the way render_video.py binds the name (`from gmpi.core.mpi_renderer import MPIRenderer`) after install()
         from gmpi.core.mpi_renderer import MPIRenderer
         assert MPIRenderer is ml_gmpi_amd.MPIRenderer
+        import sys
+        if "gmpi.core.light_renderer" in sys.modules:   # importable only where torchvision (or a stand-in) is present
+            assert sys.modules["gmpi.core.light_renderer"].LightRenderer is ml_gmpi_amd.LightRenderer
     finally:
         ml_gmpi_amd.uninstall()
     assert ns.mpi.MPI is orig_mpi and ns.mpi_renderer.MPIRenderer is orig_renderer
