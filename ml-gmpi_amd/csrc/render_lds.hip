@@ -60,10 +60,11 @@ template <int TW> constexpr int lds_bytes() { return kChunk * kRecBytes + 2 * Ti
 static_assert(lds_bytes<32>() <= 53 * 1024 && lds_bytes<64>() <= 53 * 1024, "3 workgroups per CU");
 
 // Loader geometry: one item = 16 bytes of storage = TPI texels; a box line holds kPitch/TPI items.
-template <int TPI, int TW> struct LoaderCfg {
+// (LPR = lines per texel row: 4 (row,channel) lines in the planar layout, 1 in the texel-interleaved one)
+template <int TPI, int TW, int LPR> struct LoaderCfg {
     static constexpr int kCols = TileCfg<TW>::kPitch / TPI;        // 32-wide tiles: 14 (fp32) / 7 (16-bit) items per line
     static constexpr int kLinesPerPass = kNT / kCols;            // 36 / 73 lines per pass
-    static constexpr int kNL = (TileCfg<TW>::kMaxLines + kLinesPerPass - 1) / kLinesPerPass;  // 3 / 2 passes at most
+    static constexpr int kNL = (TileCfg<TW>::kMaxLines / 4 * LPR + kLinesPerPass - 1) / kLinesPerPass;  // 3 / 2 passes at most
 };
 
 // Per-plane record of the current chunk (LDS), written once per plane by one thread so that the 8 waves do not repeat
@@ -82,12 +83,18 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename TexT> struct Quad;
 template <> struct Quad<float> {
     static constexpr int kTexels = 4;
+    static constexpr uint32_t kOneBits = 0;
+    static __device__ __forceinline__ void unpack2(uint32_t, float&, float&) {}
     static __device__ __forceinline__ void cvt(const u32x4& v, float4 (&o)[1]) {
         o[0] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
 };
 template <> struct Quad<bf16_t> {
     static constexpr int kTexels = 8;
+    static constexpr uint32_t kOneBits = 0x3f80u;  // 1.0 as a 16-bit pattern
+    static __device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi) {
+        lo = __uint_as_float(v << 16), hi = __uint_as_float(v & 0xffff0000u);
+    }
     static __device__ __forceinline__ void cvt(const u32x4& v, float4 (&o)[2]) {
         o[0] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
                            __uint_as_float(v.y & 0xffff0000u));
@@ -97,6 +104,12 @@ template <> struct Quad<bf16_t> {
 };
 template <> struct Quad<f16_t> {
     static constexpr int kTexels = 8;
+    static constexpr uint32_t kOneBits = 0x3c00u;
+    static __device__ __forceinline__ void unpack2(uint32_t v, float& lo, float& hi) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 a = __builtin_bit_cast(h2, v);
+        lo = static_cast<float>(a.x), hi = static_cast<float>(a.y);
+    }
     static __device__ __forceinline__ void cvt(const u32x4& v, float4 (&o)[2]) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const uint32_t vx = v.x, vy = v.y, vz = v.z, vw = v.w;  // (bit_cast of an ext-vector element lvalue reads element 0)
@@ -117,14 +130,20 @@ __device__ __forceinline__ bool quad_out_of_unit(const float4& q) {
 }
 
 // TW x TH pixel tile, one pixel per thread: lane = (x = tid % TW, y = tid / TW).
-template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF>
+// LAYOUT 0: LDS tile = fp32 planes [row][channel][x], one loader item = 16 bytes of one channel row.
+// LAYOUT 1 (16-bit volumes): LDS tile = the raw 16-bit texels, interleaved [row][x][RGBA] (8 bytes per texel); one loader
+//   item = a texel pair (x, x+1) of all four channels (4 dword loads, 4 v_perm, one 16-byte store).  A pixel's 16 taps
+//   are two ds_read2_b64 (32 bytes instead of 64), unpacked to fp32 in registers.
+template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF, int LAYOUT>
 __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y,
                                                                const int n_tiles) {
+    static_assert(LAYOUT == 0 || sizeof(TexT) == 2, "the interleaved layout stores raw 16-bit texels");
     using Q = Quad<TexT>;
-    using LC = LoaderCfg<Q::kTexels, TW>;
+    constexpr int LPR = LAYOUT == 1 ? 1 : 4;
+    using LC = LoaderCfg<(LAYOUT == 1 ? 2 : Q::kTexels), TW, LPR>;
     constexpr int kPitch = TileCfg<TW>::kPitch, kMaxLines = TileCfg<TW>::kMaxLines, kMaxRows = kMaxLines / 4;
     constexpr int kCapFloats = kMaxLines * kPitch, kLdsBytes = lds_bytes<TW>();
-    constexpr int TPI = Q::kTexels, kCols = LC::kCols, kRowcPerPass = LC::kLinesPerPass, kNL = LC::kNL;
+    constexpr int TPI = LAYOUT == 1 ? 2 : Q::kTexels, kCols = LC::kCols, kRowcPerPass = LC::kLinesPerPass, kNL = LC::kNL;
     constexpr int TH = kNT / TW;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
@@ -203,15 +222,16 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // (integer division runs on the VALU: readfirstlane tells the compiler the results are wave-uniform, so the
         //  `r < npass` tests below become scalar branches instead of exec-mask regions with vmcnt(0) at their ends)
         perpass = __builtin_amdgcn_readfirstlane(kNT / cols);
-        npass = __builtin_amdgcn_readfirstlane((4 * max_rows + perpass - 1) / perpass);  // <= kNL: fewer columns -> more lines per pass
+        npass = __builtin_amdgcn_readfirstlane((LPR * max_rows + perpass - 1) / perpass);  // <= kNL: fewer columns -> more lines per pass
         lrowc = tid / cols;
         lcol = tid - lrowc * cols;
-        dst_base = lrowc * (kPitch / 4) + lcol * (TPI / 4);
+        dst_base = LAYOUT == 1 ? lrowc * (kPitch / 2) + lcol : lrowc * (kPitch / 4) + lcol * (TPI / 4);  // in 16-byte units
         if (lrowc >= perpass) lcol = 0x3fffffff;  // the last 512 % cols threads load nothing: every column test fails
 #pragma unroll
         for (int r = 0; r < kNL; ++r) {
             const int rowc = lrowc + r * perpass;
-            g_off[r] = static_cast<uint32_t>((rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) * static_cast<uint32_t>(sizeof(TexT));
+            g_off[r] = static_cast<uint32_t>(LAYOUT == 1 ? rowc * s_row + TPI * lcol : (rowc & 3) * s_chan + (rowc >> 2) * s_row + TPI * lcol) *
+                       static_cast<uint32_t>(sizeof(TexT));
         }
     };
 
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                         const int clo = min(max(-ri.x / TPI, 0), ri.z), chi = min(max((Wt - ri.x) / TPI, 0), ri.z);
                         const int rlo = min(max(-by0, 0), ri.w), rhi = min(max(Ht - by0, 0), ri.w);
                         cols = ri.z | clo << 8 | (chi - clo) << 16;
-                        lines = 4 * ri.w | 4 * rlo << 8 | 4 * (rhi - rlo) << 16;
+                        lines = LPR * ri.w | LPR * rlo << 8 | LPR * (rhi - rlo) << 16;
                     }
                 }
                 nq_bits |= ri.z < 0 ? 0x80000000u : 1u << ri.z;
@@ -290,6 +310,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // One buffer resource per plane (its 4 channel images); items that fall outside the box or outside the
         // texture get the offset 0x80000000, which the hardware range check turns into zeros without touching
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
+        const int chan_bytes = __builtin_amdgcn_readfirstlane(static_cast<int>(s_chan * static_cast<int64_t>(sizeof(TexT))));
         // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
         auto issue_loads = [&](auto np, int t, u32x4 (&L)[decltype(np)::value], bool (&in_box)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;  // passes of this chunk's loader map (compile-time: see run_staged)
@@ -323,21 +344,61 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                 in_box[r] = col_in_box & (lrowc + r * perpass < (lines & 0xff));
                 const bool ok = col_ok & (static_cast<unsigned>(lrowc + (r * perpass - llo)) < static_cast<unsigned>(nline));
                 const uint32_t off = ok ? g_off[r] : 0x80000000u;  // == num_records: rejected; off+15 cannot wrap
-                L[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                if constexpr (LAYOUT == 1) {  // the pair (x, x+1) of the four channel images: scalar offset = channel
+                    L[r].x = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+                    L[r].y = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, chan_bytes, 0);
+                    L[r].z = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 2 * chan_bytes, 0);
+                    L[r].w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 3 * chan_bytes, 0);
+                } else {
+                    L[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                }
             }
         };
         auto store_box = [&](auto np, float* tile, u32x4 (&L)[decltype(np)::value], const bool (&in_box)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;
+            if constexpr (LAYOUT == 1) {
+                // item = (R, G, B, A) dwords of the texel pair (x, x+1): two v_perm per texel interleave them to
+                // [r g | b a] (8 bytes per texel); the pair goes out as one 16-byte store
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                u32x4* dst = reinterpret_cast<u32x4*>(tile) + dst_base;
+                const int pass_stride = perpass * (kPitch / 2);
+                us2 m2 = {0, 0};
+#pragma unroll
+                for (int r = 0; r < NP; ++r) {
+                    const uint32_t R = L[r].x, G = L[r].y, B = L[r].z, A = L[r].w;
+                    u32x4 o;
+                    o.x = __builtin_amdgcn_perm(G, R, 0x05040100u);  // texel x:   (g0 : r0)
+                    o.y = __builtin_amdgcn_perm(A, B, 0x05040100u);  //            (a0 : b0)
+                    o.z = __builtin_amdgcn_perm(G, R, 0x07060302u);  // texel x+1: (g1 : r1)
+                    o.w = __builtin_amdgcn_perm(A, B, 0x07060302u);  //            (a1 : b1)
+                    if (in_box[r]) dst[r * pass_stride] = o;
+                    m2 = __builtin_elementwise_max(m2, __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(us2, R), __builtin_bit_cast(us2, G)),
+                                                                                  __builtin_elementwise_max(__builtin_bit_cast(us2, B), __builtin_bit_cast(us2, A))));
+                }
+                // [0,1] test on the 16-bit patterns (ordered like unsigned ints for non-negative values); -0.0 is legal
+                if (check_range && __builtin_expect(max(m2.x, m2.y) > Q::kOneBits, 0)) {
+                    auto ok = [](uint32_t h) { return h <= Q::kOneBits || h == 0x8000u; };
+#pragma unroll
+                    for (int r = 0; r < NP; ++r) {
+                        const uint32_t d[4] = {L[r].x, L[r].y, L[r].z, L[r].w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (!(ok(d[c] & 0xffffu) && ok(d[c] >> 16))) bad |= 2u;
+                    }
+                }
+                return;
+            }
             // LDS slot of item r: line (lrowc + perpass*r), floats [TPI*lcol, TPI*lcol + TPI)
             float4* dst = reinterpret_cast<float4*>(tile) + dst_base;
             const int pass_stride = perpass * (kPitch / 4);
             uint32_t mx = 0;  // max of the fp32 bit patterns staged by this lane (lanes outside the box hold zeros)
+            constexpr int NQ = Q::kTexels / 4;  // float4 per item
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
-                float4 q[TPI / 4];
+                float4 q[NQ];
                 Q::cvt(L[r], q);
 #pragma unroll
-                for (int h = 0; h < TPI / 4; ++h) {
+                for (int h = 0; h < NQ; ++h) {
                     mx = max(max(mx, __float_as_uint(q[h].x)), max(max(__float_as_uint(q[h].y), __float_as_uint(q[h].z)), __float_as_uint(q[h].w)));
                     if (in_box[r]) dst[r * pass_stride + h] = q[h];
                 }
@@ -347,10 +408,10 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             if (check_range && __builtin_expect(mx > 0x3f800000u, 0)) {
 #pragma unroll
                 for (int r = 0; r < NP; ++r) {
-                    float4 q[TPI / 4];
+                    float4 q[NQ];
                     Q::cvt(L[r], q);
 #pragma unroll
-                    for (int h = 0; h < TPI / 4; ++h)
+                    for (int h = 0; h < NQ; ++h)
                         if (quad_out_of_unit(q[h])) bad |= 2u;
                 }
             }
@@ -380,23 +441,43 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             const int lx = static_cast<int>(floorf(ix)) - rg.y, ly = static_cast<int>(floorf(iy)) - rg.z;
             // unsigned + clamped: keeps wild coordinates (NaN rays) inside the buffer and proves the base non-negative,
             // so the 8 tap-pair reads become ds_read2_b32 with immediate offsets
-            const uint32_t idx = min(static_cast<uint32_t>(__mul24(ly, 4 * kPitch) + lx), static_cast<uint32_t>(kCapFloats - 7 * kPitch - 2));
-            // LDS byte addresses of the two texel rows, made opaque to the optimiser: it would otherwise fold the
-            // buffer's constant offset into every tap address and pay one v_add per ds_read2_b32 (the instruction's
-            // offset fields are 8 bits of dwords: channel strides 0/56/112/168 fit, the staging area's base does not)
-            typedef const float __attribute__((address_space(3))) lds_cfloat;
-            uint32_t tile_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_cfloat*)tile));
-            asm volatile("" : "+s"(tile_addr));
-            uint32_t a_top = tile_addr + 4u * idx, a_bot = a_top + 16u * kPitch;
-            asm volatile("" : "+v"(a_top), "+v"(a_bot));
-            lds_cfloat* __restrict__ top = reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(a_top));
-            lds_cfloat* __restrict__ bot = reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(a_bot));
             float smp[4];
+            if constexpr (LAYOUT == 1) {
+                // texel (lx, ly) sits at 8 * (ly * kPitch + lx) bytes: the four tap texels are two ds_read2_b64
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                typedef const u32x2 __attribute__((address_space(3))) lds_ctexel;
+                const uint32_t idx = min(static_cast<uint32_t>(__mul24(ly, kPitch) + lx), static_cast<uint32_t>(kMaxRows * kPitch - kPitch - 2));
+                uint32_t tile_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const float __attribute__((address_space(3)))*)tile));
+                asm volatile("" : "+s"(tile_addr));
+                uint32_t a_tap = tile_addr + 8u * idx;
+                asm volatile("" : "+v"(a_tap));
+                lds_ctexel* __restrict__ tp = reinterpret_cast<lds_ctexel*>(static_cast<uintptr_t>(a_tap));
+                const u32x2 q_nw = tp[0], q_ne = tp[1], q_sw = tp[kPitch], q_se = tp[kPitch + 1];
+                float t_nw[4], t_ne[4], t_sw[4], t_se[4];
+                Q::unpack2(q_nw.x, t_nw[0], t_nw[1]), Q::unpack2(q_nw.y, t_nw[2], t_nw[3]);
+                Q::unpack2(q_ne.x, t_ne[0], t_ne[1]), Q::unpack2(q_ne.y, t_ne[2], t_ne[3]);
+                Q::unpack2(q_sw.x, t_sw[0], t_sw[1]), Q::unpack2(q_sw.y, t_sw[2], t_sw[3]);
+                Q::unpack2(q_se.x, t_se[0], t_se[1]), Q::unpack2(q_se.y, t_se[2], t_se[3]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float t_nw = top[c * kPitch], t_ne = top[c * kPitch + 1];
-                const float t_sw = bot[c * kPitch], t_se = bot[c * kPitch + 1];
-                smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
+                for (int c = 0; c < 4; ++c) smp[c] = bilerp<STRICT>(t_nw[c], t_ne[c], t_sw[c], t_se[c], f);
+            } else {
+                const uint32_t idx = min(static_cast<uint32_t>(__mul24(ly, 4 * kPitch) + lx), static_cast<uint32_t>(kCapFloats - 7 * kPitch - 2));
+                // LDS byte addresses of the two texel rows, made opaque to the optimiser: it would otherwise fold the
+                // buffer's constant offset into every tap address and pay one v_add per ds_read2_b32 (the instruction's
+                // offset fields are 8 bits of dwords: channel strides 0/56/112/168 fit, the staging area's base does not)
+                typedef const float __attribute__((address_space(3))) lds_cfloat;
+                uint32_t tile_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_cfloat*)tile));
+                asm volatile("" : "+s"(tile_addr));
+                uint32_t a_top = tile_addr + 4u * idx, a_bot = a_top + 16u * kPitch;
+                asm volatile("" : "+v"(a_top), "+v"(a_bot));
+                lds_cfloat* __restrict__ top = reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(a_top));
+                lds_cfloat* __restrict__ bot = reinterpret_cast<lds_cfloat*>(static_cast<uintptr_t>(a_bot));
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float t_nw = top[c * kPitch], t_ne = top[c * kPitch + 1];
+                    const float t_sw = bot[c * kPitch], t_se = bot[c * kPitch + 1];
+                    smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
+                }
             }
             blend<STRICT>(A, smp[0], smp[1], smp[2], smp[3], s, dot);
         };
@@ -487,6 +568,7 @@ bool lds_variant_supports(const KParams& p, int dtype) {
 }
 
 constexpr int kTileW = 32;
+constexpr int kLayout16 = 1;  // default LDS layout of 16-bit volumes (see render_lds_kernel)
 
 int lds_variant_query(int what) {
     switch (what) {
@@ -497,42 +579,44 @@ int lds_variant_query(int what) {
     }
 }
 
-template <typename TexT, int TW, int MINW, int PF>
+template <typename TexT, int TW, int MINW, int PF, int LAYOUT>
 static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     constexpr int TH = kNT / TW;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int n_tiles = tiles_x * tiles_y * p.N;
     const dim3 grid(((n_tiles + 7) / 8) * 8), block(kNT);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
-    if (ac && strict) hipLaunchKernelGGL((render_lds_kernel<TexT, true, true, TW, MINW, PF>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (ac) hipLaunchKernelGGL((render_lds_kernel<TexT, true, false, TW, MINW, PF>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (strict) hipLaunchKernelGGL((render_lds_kernel<TexT, false, true, TW, MINW, PF>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else hipLaunchKernelGGL((render_lds_kernel<TexT, false, false, TW, MINW, PF>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    if (ac && strict) hipLaunchKernelGGL((render_lds_kernel<TexT, true, true, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else if (ac) hipLaunchKernelGGL((render_lds_kernel<TexT, true, false, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else if (strict) hipLaunchKernelGGL((render_lds_kernel<TexT, false, true, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else hipLaunchKernelGGL((render_lds_kernel<TexT, false, false, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
     return hipGetLastError();
 }
 
 template <int TW, int MINW, int PF>
-static hipError_t launch_lds_w(const KParams& p, int dtype, hipStream_t stream) {
+static hipError_t launch_lds_w(const KParams& p, int dtype, int layout, hipStream_t stream) {
     switch (dtype) {
-        case 0: return launch_lds_t<float, TW, MINW, PF>(p, stream);
-        case 1: return launch_lds_t<bf16_t, TW, MINW, PF>(p, stream);
-        default: return launch_lds_t<f16_t, TW, MINW, PF>(p, stream);
+        case 0: return launch_lds_t<float, TW, MINW, PF, 0>(p, stream);
+        case 1: return layout == 1 ? launch_lds_t<bf16_t, TW, MINW, PF, 1>(p, stream) : launch_lds_t<bf16_t, TW, MINW, PF, 0>(p, stream);
+        default: return layout == 1 ? launch_lds_t<f16_t, TW, MINW, PF, 1>(p, stream) : launch_lds_t<f16_t, TW, MINW, PF, 0>(p, stream);
     }
 }
 
 hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
     // experiment knobs (environment): GMPI_TUNE_PF 1|2|3 = planes of prefetch, GMPI_TUNE_TW 32|64 = tile width,
+    // GMPI_TUNE_LAYOUT 0|1 = LDS layout of 16-bit volumes (fp32 planes | raw interleaved texels),
     // GMPI_TUNE_SKIP = ablation bits (see flags bits 16-19)
     static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 1; }();
     static const int tw = [] { const char* e = getenv("GMPI_TUNE_TW"); return e ? atoi(e) : kTileW; }();
+    static const int layout = [] { const char* e = getenv("GMPI_TUNE_LAYOUT"); return e ? atoi(e) : kLayout16; }();
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
     p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores, 8 = static loader map
-    if (tw == 64) return launch_lds_w<64, 6, 1>(p, dtype, stream);
+    if (tw == 64) return launch_lds_w<64, 6, 1>(p, dtype, 0, stream);
     switch (pf) {
-        case 1: return launch_lds_w<32, 6, 1>(p, dtype, stream);
-        case 3: return launch_lds_w<32, 6, 3>(p, dtype, stream);
-        default: return launch_lds_w<32, 6, 2>(p, dtype, stream);
+        case 2: return launch_lds_w<32, 6, 2>(p, dtype, 0, stream);
+        case 3: return launch_lds_w<32, 6, 3>(p, dtype, 0, stream);
+        default: return launch_lds_w<32, 6, 1>(p, dtype, layout, stream);
     }
 }
 

@@ -63,7 +63,7 @@ import oracle
 from test_hip_parity import _random_case, hip_render
 for cfg in (dict(seed=41, B=2, D=9, S=128), dict(seed=42, B=2, D=5, S=128, extreme=True), dict(seed=43, B=1, D=97, S=64)):
     rgba, dhw, ray, eye, zd = _random_case(**cfg)
-    for vol in (rgba, rgba.to(torch.bfloat16)):
+    for vol in (rgba, rgba.to(torch.bfloat16), rgba.to(torch.float16)):
         orc = oracle.render(vol.float(), dhw, ray, eye, zd)
         out = hip_render(vol, dhw, ray, eye, zd, variant="lds", strict=True)
         for k in ("color", "depth", "T"):
@@ -73,7 +73,7 @@ print("KNOBS-OK")
 
 
 @pytest.mark.parametrize("env", [{"GMPI_TUNE_PF": "2"}, {"GMPI_TUNE_PF": "3"}, {"GMPI_TUNE_TW": "64"},
-                                 {"GMPI_TUNE_SKIP": "8"}])
+                                 {"GMPI_TUNE_SKIP": "8"}, {"GMPI_TUNE_LAYOUT": "0"}, {"GMPI_TUNE_LAYOUT": "1"}])
 def test_experiment_knobs_keep_bit_exactness(env):
     """The knobs are read once per process, hence a subprocess per setting."""
     e = dict(os.environ, **env)
