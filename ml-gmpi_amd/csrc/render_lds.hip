@@ -131,22 +131,25 @@ __device__ __forceinline__ bool quad_out_of_unit(const float4& q) {
 
 // TW x TH pixel tile, one pixel per thread: lane = (x = tid % TW, y = tid / TW).
 // LAYOUT 0: LDS tile = fp32 planes [row][channel][x], one loader item = 16 bytes of one channel row.
-// LAYOUT 1 (16-bit volumes): LDS tile = the raw 16-bit texels, interleaved [row][x][RGBA] (8 bytes per texel); one loader
-//   item = a texel pair (x, x+1) of all four channels (4 dword loads, 4 v_perm, one 16-byte store).  A pixel's 16 taps
-//   are two ds_read2_b64 (32 bytes instead of 64), unpacked to fp32 in registers.
+// LAYOUT 1: LDS tile = the raw texels, interleaved [row][x][RGBA] (8 bytes per 16-bit texel, 16 per fp32 texel); one
+//   loader item = 16 bytes of LDS = the four channels of a texel pair (16-bit: 4 dword loads, 4 v_perm) or of one texel
+//   (fp32: 4 dword loads), one 16-byte store.  A pixel's 16 taps are two ds_read2_b64 (16-bit: 32 bytes instead of 64,
+//   unpacked to fp32 in registers) or four ds_read_b128 (fp32: 8 lanes per LDS pass, so the bank wrap of a stretched
+//   row only bites when a texel is skipped inside 8 pixels).
 template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF, int LAYOUT>
 __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y,
                                                                const int n_tiles) {
-    static_assert(LAYOUT == 0 || sizeof(TexT) == 2, "the interleaved layout stores raw 16-bit texels");
     using Q = Quad<TexT>;
     constexpr int LPR = LAYOUT == 1 ? 1 : 4;
-    using LC = LoaderCfg<(LAYOUT == 1 ? 2 : Q::kTexels), TW, LPR>;
+    constexpr int kTexelBytes = 4 * static_cast<int>(sizeof(TexT));  // interleaved layout: RGBA of one texel
+    using LC = LoaderCfg<(LAYOUT == 1 ? 16 / kTexelBytes : Q::kTexels), TW, LPR>;
     constexpr int kPitch = TileCfg<TW>::kPitch, kMaxLines = TileCfg<TW>::kMaxLines, kMaxRows = kMaxLines / 4;
     constexpr int kCapFloats = kMaxLines * kPitch, kLdsBytes = lds_bytes<TW>();
-    constexpr int TPI = LAYOUT == 1 ? 2 : Q::kTexels, kCols = LC::kCols, kRowcPerPass = LC::kLinesPerPass, kNL = LC::kNL;
+    constexpr int TPI = LAYOUT == 1 ? 16 / kTexelBytes : Q::kTexels, kCols = LC::kCols, kRowcPerPass = LC::kLinesPerPass, kNL = LC::kNL;
     constexpr int TH = kNT / TW;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
+    __shared__ int box_max[2];  // largest item count per row / row count of the chunk's boxes (ds_max_i32 reduction)
     int4* tabL = reinterpret_cast<int4*>(smem);
     float4* tabF = reinterpret_cast<float4*>(smem + kChunk * 16);
     int4* tabG = reinterpret_cast<int4*>(smem + kChunk * 32);
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         npass = __builtin_amdgcn_readfirstlane((LPR * max_rows + perpass - 1) / perpass);  // <= kNL: fewer columns -> more lines per pass
         lrowc = tid / cols;
         lcol = tid - lrowc * cols;
-        dst_base = LAYOUT == 1 ? lrowc * (kPitch / 2) + lcol : lrowc * (kPitch / 4) + lcol * (TPI / 4);  // in 16-byte units
+        dst_base = LAYOUT == 1 ? lrowc * (kPitch / TPI) + lcol : lrowc * (kPitch / 4) + lcol * (TPI / 4);  // in 16-byte units
         if (lrowc >= perpass) lcol = 0x3fffffff;  // the last 512 % cols threads load nothing: every column test fails
 #pragma unroll
         for (int r = 0; r < kNL; ++r) {
@@ -242,9 +245,10 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         //      and the largest item count per row / row count of the chunk (for the loader map) -----------------
         int max_nq = kCols, max_rows = kMaxRows;
         auto build_table = [&](int y_lo, int y_hi) -> bool {
-            __syncthreads();  // the previous table / staging buffers are no longer read
-            uint32_t nq_bits = 0, row_bits = 0;  // one-hot: the workgroup OR's highest bit is the maximum
-            // (__ockl_wgred_or_i32 = barrier + bitwise OR over the workgroup; __syncthreads_or would reduce !!x)
+            __syncthreads();  // the previous table / staging buffers / maxima are no longer read
+            if (tid < 2) box_max[tid] = 0;
+            __syncthreads();
+            int nq_max = 0, row_max = 0;  // (a box that does not fit counts as 1 << 20 items)
             for (int t = tid; t < kn; t += kNT) {
                 const int k = kc + t;
                 const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
@@ -277,19 +281,21 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
                         lines = LPR * ri.w | LPR * rlo << 8 | LPR * (rhi - rlo) << 16;
                     }
                 }
-                nq_bits |= ri.z < 0 ? 0x80000000u : 1u << ri.z;
-                row_bits |= 1u << (ri.w & 31);
+                nq_max = max(nq_max, ri.z < 0 ? 1 << 20 : ri.z);
+                row_max = max(row_max, ri.w);
                 const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
                 const uint64_t origin = reinterpret_cast<uint64_t>(vol + (static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(ri.y) * s_row + ri.x));
                 tabL[t] = make_int4(static_cast<int>(origin & 0xffffffffu), static_cast<int>((origin >> 32) & 0xffffu), cols, lines);
                 tabF[t] = make_float4(zdiff, hw, hh, 1.0f / hw);
                 tabG[t] = make_int4(__float_as_int(1.0f / hh), ri.x, ri.y, 0);
             }
-            const uint32_t a = __builtin_amdgcn_readfirstlane(__ockl_wgred_or_i32(static_cast<int>(nq_bits)));  // also publishes the table
-            const uint32_t b = __builtin_amdgcn_readfirstlane(__ockl_wgred_or_i32(static_cast<int>(row_bits)));
-            max_nq = 31 - __builtin_clz((a & 0x7fffffffu) | 1u);
-            max_rows = 31 - __builtin_clz(b | 1u);
-            return (a >> 31) != 0;
+            if (tid < kn) atomicMax(&box_max[0], nq_max), atomicMax(&box_max[1], row_max);
+            __syncthreads();  // table and maxima published
+            max_nq = __builtin_amdgcn_readfirstlane(box_max[0]);
+            max_rows = __builtin_amdgcn_readfirstlane(box_max[1]);
+            const bool unfit = max_nq >= (1 << 20);
+            max_nq = max(min(max_nq, kCols), 1), max_rows = max(min(max_rows, kMaxRows), 1);
+            return unfit;
         };
 
         // ---- last resort (texture much finer than the image, degenerate rays): direct gather, same arithmetic ----
@@ -356,7 +362,23 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         };
         auto store_box = [&](auto np, float* tile, u32x4 (&L)[decltype(np)::value], const bool (&in_box)[decltype(np)::value]) {
             constexpr int NP = decltype(np)::value;
-            if constexpr (LAYOUT == 1) {
+            if constexpr (LAYOUT == 1 && sizeof(TexT) == 4) {
+                // item = (R, G, B, A) of one texel, already in storage order: one 16-byte store, no VALU
+                u32x4* dst = reinterpret_cast<u32x4*>(tile) + dst_base;
+                const int pass_stride = perpass * kPitch;
+                uint32_t mx = 0;
+#pragma unroll
+                for (int r = 0; r < NP; ++r) {
+                    if (in_box[r]) dst[r * pass_stride] = L[r];
+                    mx = max(max(mx, L[r].x), max(max(L[r].y, L[r].z), L[r].w));
+                }
+                if (check_range && __builtin_expect(mx > 0x3f800000u, 0)) {
+#pragma unroll
+                    for (int r = 0; r < NP; ++r)
+                        if (quad_out_of_unit(make_float4(__uint_as_float(L[r].x), __uint_as_float(L[r].y), __uint_as_float(L[r].z), __uint_as_float(L[r].w)))) bad |= 2u;
+                }
+                return;
+            } else if constexpr (LAYOUT == 1) {
                 // item = (R, G, B, A) dwords of the texel pair (x, x+1): two v_perm per texel interleave them to
                 // [r g | b a] (8 bytes per texel); the pair goes out as one 16-byte store
                 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -442,7 +464,20 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             // unsigned + clamped: keeps wild coordinates (NaN rays) inside the buffer and proves the base non-negative,
             // so the 8 tap-pair reads become ds_read2_b32 with immediate offsets
             float smp[4];
-            if constexpr (LAYOUT == 1) {
+            if constexpr (LAYOUT == 1 && sizeof(TexT) == 4) {
+                // texel (lx, ly) = 16 bytes at 16 * (ly * kPitch + lx): the four tap texels are four ds_read_b128
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef const f32x4 __attribute__((address_space(3))) lds_ctexel4;
+                const uint32_t idx = min(static_cast<uint32_t>(__mul24(ly, kPitch) + lx), static_cast<uint32_t>(kMaxRows * kPitch - kPitch - 2));
+                uint32_t tile_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((const float __attribute__((address_space(3)))*)tile));
+                asm volatile("" : "+s"(tile_addr));
+                uint32_t a_tap = tile_addr + 16u * idx;
+                asm volatile("" : "+v"(a_tap));
+                lds_ctexel4* __restrict__ tp = reinterpret_cast<lds_ctexel4*>(static_cast<uintptr_t>(a_tap));
+                const f32x4 q_nw = tp[0], q_ne = tp[1], q_sw = tp[kPitch], q_se = tp[kPitch + 1];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) smp[c] = bilerp<STRICT>(q_nw[c], q_ne[c], q_sw[c], q_se[c], f);
+            } else if constexpr (LAYOUT == 1) {
                 // texel (lx, ly) sits at 8 * (ly * kPitch + lx) bytes: the four tap texels are two ds_read2_b64
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 typedef const u32x2 __attribute__((address_space(3))) lds_ctexel;
@@ -569,6 +604,7 @@ bool lds_variant_supports(const KParams& p, int dtype) {
 
 constexpr int kTileW = 32;
 constexpr int kLayout16 = 1;  // default LDS layout of 16-bit volumes (see render_lds_kernel)
+constexpr int kLayout32 = 0;  // ... of fp32 volumes
 
 int lds_variant_query(int what) {
     switch (what) {
@@ -594,9 +630,9 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
 }
 
 template <int TW, int MINW, int PF>
-static hipError_t launch_lds_w(const KParams& p, int dtype, int layout, hipStream_t stream) {
+static hipError_t launch_lds_w(const KParams& p, int dtype, int layout, int layout32, hipStream_t stream) {
     switch (dtype) {
-        case 0: return launch_lds_t<float, TW, MINW, PF, 0>(p, stream);
+        case 0: return layout32 == 1 ? launch_lds_t<float, TW, MINW, PF, 1>(p, stream) : launch_lds_t<float, TW, MINW, PF, 0>(p, stream);
         case 1: return layout == 1 ? launch_lds_t<bf16_t, TW, MINW, PF, 1>(p, stream) : launch_lds_t<bf16_t, TW, MINW, PF, 0>(p, stream);
         default: return layout == 1 ? launch_lds_t<f16_t, TW, MINW, PF, 1>(p, stream) : launch_lds_t<f16_t, TW, MINW, PF, 0>(p, stream);
     }
@@ -604,19 +640,20 @@ static hipError_t launch_lds_w(const KParams& p, int dtype, int layout, hipStrea
 
 hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
     // experiment knobs (environment): GMPI_TUNE_PF 1|2|3 = planes of prefetch, GMPI_TUNE_TW 32|64 = tile width,
-    // GMPI_TUNE_LAYOUT 0|1 = LDS layout of 16-bit volumes (fp32 planes | raw interleaved texels),
+    // GMPI_TUNE_LAYOUT / GMPI_TUNE_LAYOUT32 0|1 = LDS layout of 16-bit / fp32 volumes (fp32 planes | raw interleaved texels),
     // GMPI_TUNE_SKIP = ablation bits (see flags bits 16-19)
     static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 1; }();
     static const int tw = [] { const char* e = getenv("GMPI_TUNE_TW"); return e ? atoi(e) : kTileW; }();
     static const int layout = [] { const char* e = getenv("GMPI_TUNE_LAYOUT"); return e ? atoi(e) : kLayout16; }();
+    static const int layout32 = [] { const char* e = getenv("GMPI_TUNE_LAYOUT32"); return e ? atoi(e) : kLayout32; }();
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
     p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores, 8 = static loader map
-    if (tw == 64) return launch_lds_w<64, 6, 1>(p, dtype, 0, stream);
+    if (tw == 64) return launch_lds_w<64, 6, 1>(p, dtype, 0, 0, stream);
     switch (pf) {
-        case 2: return launch_lds_w<32, 6, 2>(p, dtype, 0, stream);
-        case 3: return launch_lds_w<32, 6, 3>(p, dtype, 0, stream);
-        default: return launch_lds_w<32, 6, 1>(p, dtype, layout, stream);
+        case 2: return launch_lds_w<32, 6, 2>(p, dtype, 0, 0, stream);
+        case 3: return launch_lds_w<32, 6, 3>(p, dtype, 0, 0, stream);
+        default: return launch_lds_w<32, 6, 1>(p, dtype, layout, layout32, stream);
     }
 }
 
