@@ -80,3 +80,46 @@ def test_experiment_knobs_keep_bit_exactness(env):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", _KNOB_SCRIPT, ROOT], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "KNOBS-OK" in r.stdout, (env, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def _fuzz_case(rng):
+    """Random small problem: non-square image and texture, any storage type, random or extreme poses."""
+    from ml_gmpi_amd.renderer import MPIRenderer, PRESETS
+    H, W = int(rng.integers(8, 150)), int(rng.integers(8, 150))
+    Ht, Wt = 8 * int(rng.integers(1, 24)), 8 * int(rng.integers(1, 24))
+    D, B = int(rng.integers(1, 10)), int(rng.integers(1, 4))
+    preset = ["FFHQ", "AFHQCat", "MetFaces"][int(rng.integers(0, 3))]
+    ac = bool(rng.integers(0, 2))
+    kw = dict(PRESETS[preset])
+    kw.update(n_mpi_planes=D, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse",
+              cam_sample_method="truncated_gaussian", mpi_align_corners=ac, use_confined_volume=True, device=torch.device("cpu"))
+    r = MPIRenderer(**kw)
+    r.set_cam(r.cam_fov, max(H, W), max(H, W))   # the reference's camera is square (mpi_renderer.py:84): crop the rays
+    seed = int(rng.integers(0, 2 ** 31))
+    rgba = torch.rand((B, D, 4, Ht, Wt), generator=torch.Generator().manual_seed(seed))
+    torch.manual_seed(seed)
+    if rng.integers(0, 2):
+        n = r.cam_pose_n_truncated_stds
+        gy = torch.tensor([[(-1) ** i * n * r.horizontal_std] for i in range(B)], dtype=torch.float32)
+        gp = torch.tensor([[(-1) ** (i // 2) * n * r.vertical_std] for i in range(B)], dtype=torch.float32)
+        cam = r.sample_cam_poses(B, 0, 0, 0, 0, False, given_yaws=gy, given_pitches=gp)
+    else:
+        cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    dhw = r.static_mpi_plane_dhws.reshape(1, -1, 3).expand(B, -1, -1).contiguous()
+    dtype = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+    ray = torch.cat(cam[3])[:, :, :H, :W].contiguous()
+    return dict(H=H, W=W, Ht=Ht, Wt=Wt, D=D, B=B, preset=preset, ac=ac, dtype=dtype), (rgba.to(dtype), dhw, ray, torch.cat(cam[4]), torch.cat(cam[5]))
+
+
+def test_fuzz_strict_mode_is_bit_exact_on_random_small_problems():
+    rng = np.random.default_rng(20260925)
+    for i in range(24):
+        cfg, (vol, dhw, ray, eye, zd) = _fuzz_case(rng)
+        orc = oracle.render(vol.float(), dhw, ray, eye, zd, align_corners=cfg["ac"])
+        for variant in ("lds", "gather"):
+            out = hip_render(vol, dhw, ray, eye, zd, ac=cfg["ac"], variant=variant, strict=True, check_last=False)
+            for k in ("color", "depth", "T"):
+                assert np.array_equal(out[k], orc[k]), (i, cfg, variant, k, float(np.abs(out[k] - orc[k]).max()))
+        fast = hip_render(vol, dhw, ray, eye, zd, ac=cfg["ac"], variant="lds", check_last=False)
+        assert np.abs(fast["color"] - orc["color"]).max() <= 0.5 * TOL, (i, cfg)
+        assert np.abs(fast["depth"] - orc["depth"]).max() <= TOL, (i, cfg)
