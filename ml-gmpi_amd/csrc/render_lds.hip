@@ -144,7 +144,9 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     constexpr int kTexelBytes = 4 * static_cast<int>(sizeof(TexT));  // interleaved layout: RGBA of one texel
     using LC = LoaderCfg<(LAYOUT == 1 ? 16 / kTexelBytes : Q::kTexels), TW, LPR>;
     constexpr int kPitch = TileCfg<TW>::kPitch, kMaxLines = TileCfg<TW>::kMaxLines, kMaxRows = kMaxLines / 4;
-    constexpr int kCapFloats = kMaxLines * kPitch, kLdsBytes = lds_bytes<TW>();
+    // floats per staging buffer: fp32 planes / fp32 texels need 4 per texel-channel, raw 16-bit texels half of that
+    constexpr int kCapFloats = (LAYOUT == 1 && sizeof(TexT) == 2) ? kMaxLines * kPitch / 2 : kMaxLines * kPitch;
+    constexpr int kLdsBytes = kChunk * kRecBytes + 2 * kCapFloats * 4;
     constexpr int TPI = LAYOUT == 1 ? 16 / kTexelBytes : Q::kTexels, kCols = LC::kCols, kRowcPerPass = LC::kLinesPerPass, kNL = LC::kNL;
     constexpr int TH = kNT / TW;
 
@@ -646,6 +648,9 @@ hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
     static const int tw = [] { const char* e = getenv("GMPI_TUNE_TW"); return e ? atoi(e) : kTileW; }();
     static const int layout = [] { const char* e = getenv("GMPI_TUNE_LAYOUT"); return e ? atoi(e) : kLayout16; }();
     static const int layout32 = [] { const char* e = getenv("GMPI_TUNE_LAYOUT32"); return e ? atoi(e) : kLayout32; }();
+    // waves/SIMD the register allocator targets for 16-bit volumes in the interleaved layout (29 KB of LDS per workgroup:
+    // 4 workgroups per CU at 64 VGPRs; the spills stay outside the plane loop; +3.5 % over 6 waves/SIMD, r01_ablation.txt)
+    static const int minw = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 8; }();
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
     p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores, 8 = static loader map
@@ -653,7 +658,9 @@ hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
     switch (pf) {
         case 2: return launch_lds_w<32, 6, 2>(p, dtype, 0, 0, stream);
         case 3: return launch_lds_w<32, 6, 3>(p, dtype, 0, 0, stream);
-        default: return launch_lds_w<32, 6, 1>(p, dtype, layout, layout32, stream);
+        default:
+            if (minw == 8 && dtype != 0 && layout == 1) return launch_lds_w<32, 8, 1>(p, dtype, 1, 0, stream);
+            return launch_lds_w<32, 6, 1>(p, dtype, layout, layout32, stream);
     }
 }
 

@@ -74,7 +74,7 @@ print("KNOBS-OK")
 
 @pytest.mark.parametrize("env", [{"GMPI_TUNE_PF": "2"}, {"GMPI_TUNE_PF": "3"}, {"GMPI_TUNE_TW": "64"},
                                  {"GMPI_TUNE_SKIP": "8"}, {"GMPI_TUNE_LAYOUT": "0"}, {"GMPI_TUNE_LAYOUT": "1"},
-                                 {"GMPI_TUNE_LAYOUT32": "0"}, {"GMPI_TUNE_LAYOUT32": "1"}])
+                                 {"GMPI_TUNE_LAYOUT32": "0"}, {"GMPI_TUNE_LAYOUT32": "1"}, {"GMPI_TUNE_MINW": "6"}])
 def test_experiment_knobs_keep_bit_exactness(env):
     """The knobs are read once per process, hence a subprocess per setting."""
     e = dict(os.environ, **env)

@@ -35,6 +35,20 @@ __global__ void k(float* out, int iters, long long* cyc) {
             REP16(asm volatile("v_floor_f32 %0, %0\n v_cvt_i32_f32 %1, %1\n v_floor_f32 %2, %2\n v_cvt_i32_f32 %3, %3\n"
                                "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %4\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
+        } else if (MODE == 6) {  // bf16 unpack the integer way: v_lshlrev_b32 16 / v_and_b32 0xffff0000
+            REP16(asm volatile("v_lshlrev_b32 %0, 16, %1\n v_and_b32 %1, 0xffff0000, %2\n v_lshlrev_b32 %2, 16, %3\n v_and_b32 %3, 0xffff0000, %4\n"
+                               "v_lshlrev_b32 %4, 16, %5\n v_and_b32 %5, 0xffff0000, %6\n v_lshlrev_b32 %6, 16, %7\n v_and_b32 %7, 0xffff0000, %0\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
+        } else if (MODE == 7) {  // bf16 unpack with gfx950's conversion: v_cvt_f32_bf16 (low half) / _sdwa WORD_1 (high half)
+            REP16(asm volatile("v_cvt_f32_bf16 %0, %1\n v_cvt_f32_bf16_sdwa %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                               "v_cvt_f32_bf16 %2, %3\n v_cvt_f32_bf16_sdwa %3, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                               "v_cvt_f32_bf16 %4, %5\n v_cvt_f32_bf16_sdwa %5, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                               "v_cvt_f32_bf16 %6, %7\n v_cvt_f32_bf16_sdwa %7, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
+        } else if (MODE == 8) {  // v_perm_b32 / v_readfirstlane-free integer helpers: v_perm_b32, v_max3_u32, v_cmp+v_cndmask
+            REP16(asm volatile("v_perm_b32 %0, %1, %2, %8\n v_max3_u32 %1, %2, %3, %4\n v_perm_b32 %2, %3, %4, %8\n v_max3_u32 %3, %4, %5, %6\n"
+                               "v_perm_b32 %4, %5, %6, %8\n v_max3_u32 %5, %6, %7, %0\n v_perm_b32 %6, %7, %0, %8\n v_max3_u32 %7, %0, %1, %2\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
         } else if (MODE == 5) {  // v_pk_mul_f32 + v_pk_add_f32
             REP16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n"
                                "v_pk_mul_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %5\n"
@@ -71,6 +85,7 @@ int main() {
     for (int w : {1, 2, 4}) {
         run<0>("v_fma_f32", w); run<1>("v_pk_fma_f32", w); run<2>("v_mul/add_f32", w); run<3>("v_add_u32/lshl_add", w);
         run<4>("floor/cvt/mov", w); run<5>("v_pk_mul/add_f32", w);
+        run<6>("v_lshlrev/v_and (bf16 unpack)", w); run<7>("v_cvt_f32_bf16 (+sdwa)", w); run<8>("v_perm_b32/v_max3_u32", w);
     }
     return 0;
 }
