@@ -318,6 +318,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // One buffer resource per plane (its 4 channel images); items that fall outside the box or outside the
         // texture get the offset 0x80000000, which the hardware range check turns into zeros without touching
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
+        const int load_mask = (p.flags & (1u << 16)) ? 0 : 0xff, store_mask = (p.flags & (1u << 18)) ? 0 : 0xff;  // ablation bits
         const int chan_bytes = __builtin_amdgcn_readfirstlane(static_cast<int>(s_chan * static_cast<int64_t>(sizeof(TexT))));
         // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
         auto issue_loads = [&](auto np, int t, u32x4 (&L)[decltype(np)::value], bool (&in_box)[decltype(np)::value]) {
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             // Issued UNCONDITIONALLY, also for planes past the end of the chunk (all offsets out of range then: no
             // memory access): hipcc's waitcnt insertion only lets a load stay in flight across the next plane's
             // staged store ("vmcnt(NP)" instead of "vmcnt(0)") if every path issues the same number of loads.
-            const bool live = (t < kn) & !(p.flags & (1u << 16));
-            const bool live_store = (t < kn) & !(p.flags & (1u << 18));
+            // integer masks (not bools): keeps the uniform liveness logic on the scalar unit
+            const int live = t < kn ? load_mask : 0, live_store = t < kn ? store_mask : 0;
             const int4 rl = tabL[min(t, kn - 1)];
             // the descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a waterfall loop
             // (cdna_hip_programming.md T20): pass its inputs through readfirstlane.  Base = the box origin, so the
@@ -340,13 +341,13 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             // item columns [clo, clo+ncol) and lines [llo, llo+nline) of the box lie inside the texture (one unsigned
             // compare each); everything else reads as zero ("zeros" padding) without touching memory
             // (a plane that is not live gets empty ranges: the uniform flags stay on the scalar unit)
-            const int clo = (cols >> 8) & 0xff, ncol = live ? (cols >> 16) & 0xff : 0;
+            const int clo = (cols >> 8) & 0xff, ncol = (cols >> 16) & 0xff & live;
             const int llo = (lines >> 8) & 0xff, nline = (lines >> 16) & 0xff;
             const bool col_ok = static_cast<unsigned>(lcol - clo) < static_cast<unsigned>(ncol);
             // which LDS slots the staged store of this plane has to write: the box itself (texels of it that lie
             // outside the texture are written as the zeros the loads return); lanes outside the box stay idle --
             // LDS write time goes with the number of active lanes (tools/ubench/lds_read_rate.hip)
-            const bool col_in_box = lcol < (live_store ? (cols & 0xff) : 0);
+            const bool col_in_box = lcol < (cols & 0xff & live_store);
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
                 in_box[r] = col_in_box & (lrowc + r * perpass < (lines & 0xff));
@@ -659,7 +660,8 @@ hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
         case 2: return launch_lds_w<32, 6, 2>(p, dtype, 0, 0, stream);
         case 3: return launch_lds_w<32, 6, 3>(p, dtype, 0, 0, stream);
         default:
-            if (minw == 8 && dtype != 0 && layout == 1) return launch_lds_w<32, 8, 1>(p, dtype, 1, 0, stream);
+            if (minw == 8 && dtype != 0 && layout == 1)
+                return dtype == 1 ? launch_lds_t<bf16_t, 32, 8, 1, 1>(p, stream) : launch_lds_t<f16_t, 32, 8, 1, 1>(p, stream);
             return launch_lds_w<32, 6, 1>(p, dtype, layout, layout32, stream);
     }
 }
