@@ -29,6 +29,11 @@
 //  * the loader's thread -> item map is re-derived per chunk from the largest box of the chunk, so a frontal
 //    view needs 1 pass (16-bit) / 2 passes (fp32) over the box instead of the worst-case 2 / 3;
 //  * tap addresses are kept opaque so that the 8 ds_read2_b32 use immediate offsets.
+//  * 16-bit volumes keep their raw texels in LDS, interleaved per texel (LAYOUT 1 below): half the LDS bytes, two
+//    ds_read2_b64 per pixel, and no bank wrap when a tilted view samples more than one texel per pixel along x (with
+//    fp32 planes in LDS that wrap doubles the tap cost: tools/ubench/lds_tap_pattern.hip);
+//  * the library is built with -fno-slp-vectorize: packed fp32 math (v_pk_*_f32) issues at 4.9 cycles per wave on this
+//    part against 2.8 for scalar fp32, and the packing costs extra moves.
 //
 // HBM traffic: each texel of the volume is read once per view (halo rows/columns are shared with the
 // neighbouring tiles through the XCD's L2: the blockIdx -> tile map gives every XCD a contiguous run
