@@ -25,7 +25,7 @@ def variants():
     return ["gather", "lds"] if L.load_library().gmpi_query(3) > 0 else ["gather"]
 
 
-def setup(S, D, B, preset="FFHQ", dtype=torch.float32, seed=0, last_alpha_one=False):
+def setup(S, D, B, preset="FFHQ", dtype=torch.float32, seed=0, last_alpha_one=False, extreme=False):
     from ml_gmpi_amd import make_renderer
     dev = torch.device(DEV)
     r = make_renderer(preset, n_planes=D, device=dev, on_out_of_plane="raise")
@@ -36,7 +36,13 @@ def setup(S, D, B, preset="FFHQ", dtype=torch.float32, seed=0, last_alpha_one=Fa
         rgba[:, -1, 3] = 1.0
     rgba = rgba.to(dtype)
     torch.manual_seed(seed)
-    cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    if extreme:  # the 2-sigma corner of the pose distribution: boxes shear, half-tile staging, texture borders in reach
+        n = r.cam_pose_n_truncated_stds
+        gy = torch.tensor([[(-1) ** i * n * r.horizontal_std] for i in range(B)], dtype=torch.float32)
+        gp = torch.tensor([[(-1) ** (i // 2) * n * r.vertical_std] for i in range(B)], dtype=torch.float32)
+        cam = r.sample_cam_poses(B, 0, 0, 0, 0, False, given_yaws=gy, given_pitches=gp)
+    else:
+        cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
     dhw = r._dhw_on_device().expand(B, -1, -1).contiguous()
     return r, rgba, dhw, torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
 
@@ -100,7 +106,8 @@ def test_plane_split_associativity_full_size():
         assert float((T - whole["T"]).abs().max()) <= 1e-6, variant
 
 
-@pytest.mark.parametrize("shape", [dict(S=1024, D=96, B=1, dtype=torch.bfloat16), dict(S=1024, D=256, B=1, dtype=torch.float32, preset="MetFaces")])
+@pytest.mark.parametrize("shape", [dict(S=1024, D=96, B=1, dtype=torch.bfloat16), dict(S=1024, D=256, B=1, dtype=torch.float32, preset="MetFaces"),
+                                   dict(S=1024, D=96, B=2, dtype=torch.bfloat16, extreme=True), dict(S=1024, D=96, B=1, dtype=torch.float32, extreme=True)])
 def test_full_size_window_against_oracle(shape):
     """Oracle on the rays of a few 64x64 windows of the full-size image (the volume is full size)."""
     r, rgba, dhw, ray, eye, zd = setup(seed=6, **shape)
