@@ -56,11 +56,32 @@ def gaussian_kernel1d(ksize: int, sigma: float) -> torch.Tensor:
     return pdf / pdf.sum()
 
 
-def _blur_torch(depth: torch.Tensor, k1d: torch.Tensor) -> torch.Tensor:
-    """torch restatement of gaussian_blur_kernel ([B,1,H,W]); only used to differentiate the middle of the pipeline."""
-    r = k1d.numel() // 2
-    k2d = torch.outer(k1d, k1d).to(depth)[None, None]
-    return F.conv2d(F.pad(depth, (r, r, r, r), mode="reflect"), k2d)
+_BLUR_MATRICES = {}
+
+
+def _blur_matrix(n: int, k1d: torch.Tensor, device) -> torch.Tensor:
+    """[n,n] matrix of the 1-D reflect-padded blur (row i = weights of output i over the inputs); cached."""
+    k1d = k1d.detach().cpu()
+    key = (n, tuple(k1d.tolist()), str(device))
+    m = _BLUR_MATRICES.get(key)
+    if m is None:
+        k, r = k1d.numel(), k1d.numel() // 2
+        src = torch.arange(n).view(n, 1) + torch.arange(k).view(1, k) - r          # [n,k] unpadded source index
+        src = src.abs()
+        src = torch.where(src >= n, 2 * (n - 1) - src, src)                       # padding_mode="reflect"
+        m = torch.zeros((n, n), dtype=torch.float32)
+        m.index_put_((torch.arange(n).view(n, 1).expand(n, k), src), k1d.to(torch.float32).view(1, k).expand(n, k), accumulate=True)
+        m = m.to(device)
+        if len(_BLUR_MATRICES) < 16:
+            _BLUR_MATRICES[key] = m
+    return m
+
+
+def _blur_torch(depth: torch.Tensor, my: torch.Tensor, mx: torch.Tensor) -> torch.Tensor:
+    """Differentiable restatement of gaussian_blur_kernel ([B,1,H,W]) for the backward of the pipeline's middle: the
+    separable blur as two GEMMs with the reflect-padded 1-D operators `_blur_matrix` (equal to the 81-tap sum up to
+    rounding; a 9x9 `F.conv2d` on B single-channel images costs milliseconds in MIOpen, the GEMMs microseconds)."""
+    return torch.matmul(torch.matmul(my, depth), mx.t())
 
 
 def _shading_torch(depth_blurred: torch.Tensor, xyz_last: torch.Tensor, light_dir: torch.Tensor, ka: float, kd: float) -> torch.Tensor:
@@ -84,15 +105,21 @@ class _LightFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vol, renderer, plane_ds, xyz_last, light_dir, ka, kd):
         out, depth, T, shading = renderer._forward_kernels(vol.detach(), plane_ds, xyz_last, light_dir, ka, kd)
-        ctx.save_for_backward(vol.detach(), depth, T, shading)
-        ctx.misc = (renderer._k1d, plane_ds, xyz_last, light_dir, ka, kd, vol.dtype)
+        dev = vol.device
+        H, W = vol.shape[-2:]
+        # everything the backward needs is put on the device here: CPU tensor ops inside the autograd worker thread start
+        # a second OpenMP pool, and the two pools then fight for the cores (milliseconds per tiny host op)
+        ctx.save_for_backward(vol.detach(), depth, T, shading, _blur_matrix(H, renderer._k1d, dev), _blur_matrix(W, renderer._k1d, dev),
+                              xyz_last.to(dev, torch.float32), light_dir.to(dev, torch.float32),
+                              plane_ds.reshape(-1).to(dev, torch.float32).contiguous())
+        ctx.misc = (ka, kd, vol.dtype)
         return out
 
     @staticmethod
     def backward(ctx, g_out):
         lib = _lib.load_library()
-        vol, depth, T, shading = ctx.saved_tensors
-        k1d, plane_ds, xyz_last, light_dir, ka, kd, in_dtype = ctx.misc
+        vol, depth, T, shading, my, mx, xyz_last, light_dir, ds = ctx.saved_tensors
+        ka, kd, in_dtype = ctx.misc
         dev = vol.device
         B, D, _, H, W = vol.shape
         g_out = g_out.to(torch.float32).contiguous()
@@ -106,11 +133,10 @@ class _LightFunction(torch.autograd.Function):
                                                             stream), "gmpi_light_apply_backward_launch")
         with torch.enable_grad():
             d = depth.detach().requires_grad_(True)
-            s = _shading_torch(_blur_torch(d, k1d.to(dev)), xyz_last.to(dev), light_dir.to(dev), ka, kd)
+            s = _shading_torch(_blur_torch(d, my, mx), xyz_last, light_dir, ka, kd)
             (g_depth,) = torch.autograd.grad(s, d, g_shading)
         g_depth = g_depth.contiguous()
         alpha = vol[:, :, 3:]
-        ds = plane_ds.reshape(-1).to(dev, torch.float32).contiguous()
         plane = H * W
         with torch.cuda.device(dev):
             _lib.check(lib.gmpi_alpha_depth_backward_launch(
@@ -201,9 +227,10 @@ class LightRenderer:
                                           yaw_mean=self.l_h_mean, yaw_std=self.l_h_std, pitch_mean=self.l_v_mean,
                                           pitch_std=self.l_v_std, n_truncated_stds=2, flag_rnd=True,
                                           sample_method="truncated_gaussian", given_yaws=None, given_pitches=None)
-        light_pos = c2w[:, :3, 3]
-        light_pos = light_pos if isinstance(light_pos, torch.Tensor) else torch.FloatTensor(light_pos)
-        light_direction = poses._unit(self.sphere_center.reshape(1, 3) - light_pos)  # towards the sphere centre
+        with poses.host_math():
+            light_pos = c2w[:, :3, 3]
+            light_pos = light_pos if isinstance(light_pos, torch.Tensor) else torch.FloatTensor(light_pos)
+            light_direction = poses._unit(self.sphere_center.reshape(1, 3) - light_pos)  # towards the sphere centre
         cur_ratio = min(1.0, self.step / self.n_grow_iters)
         self.cur_ka, self.cur_kd = cur_ratio * self.ka_max, cur_ratio * self.kd_max
         plane_ds = mpi_plane_dhws[:, :1].detach().to(dev)

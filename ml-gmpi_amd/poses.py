@@ -17,11 +17,40 @@ MPI/world frame: +X right, +Y down, +Z forward.
 """
 from typing import Optional, Tuple
 
+import threading
+
 import numpy as np
 import torch
 from scipy.spatial.transform import Rotation
 
 _CPU = torch.device("cpu")
+
+
+class host_math:
+    """Context for the tiny CPU tensor ops of pose sampling (a few [B,1] tensors): run them on one thread.
+
+    On a 128-core host some of these ops (`max(dim)`, `gather`, advanced indexing) open an OpenMP region over the whole
+    intra-op pool for 8 elements; waking 128 sleeping threads costs milliseconds per op and made `render()` and the
+    shading augmentation 5-10x slower than their kernels (profiles/r01_aux_kernels.txt).  The intra-op thread count is
+    process-global, so it is restored on exit; nested use is a no-op."""
+    _depth = 0
+    _lock = threading.Lock()
+
+    def __enter__(self):
+        with host_math._lock:
+            host_math._depth += 1
+            if host_math._depth == 1:
+                host_math._saved = torch.get_num_threads()
+                if host_math._saved != 1:
+                    torch.set_num_threads(1)
+        return self
+
+    def __exit__(self, *exc):
+        with host_math._lock:
+            host_math._depth -= 1
+            if host_math._depth == 0 and host_math._saved != 1:
+                torch.set_num_threads(host_math._saved)
+        return False
 
 
 def _unit(v: torch.Tensor) -> torch.Tensor:
@@ -134,15 +163,16 @@ def gen_sphere_path(n_cams: int, sphere_center: np.ndarray, sphere_r: Optional[f
     (c2w [n,4,4] float64 numpy in the MPI frame, yaws [n,1], pitches [n,1])."""
     if sphere_r is None:
         sphere_r = np.linalg.norm(sphere_center, ord=2)
-    if given_yaws is None:
-        assert given_pitches is None
-        yaws, pitches = sample_sphere_angles(n_cams, yaw_mean, yaw_std, pitch_mean, pitch_std, random=flag_rnd,
-                                             method=sample_method, n_stds=n_truncated_stds,
-                                             horizontal_sweep=flag_det_horizontal, device=device)
-    else:
-        yaws, pitches = given_yaws, given_pitches
-    pos = sphere_positions(yaws, pitches, sphere_r)
-    cam2sphere = look_at_centre(pos).cpu().numpy()
+    with host_math():
+        if given_yaws is None:
+            assert given_pitches is None
+            yaws, pitches = sample_sphere_angles(n_cams, yaw_mean, yaw_std, pitch_mean, pitch_std, random=flag_rnd,
+                                                 method=sample_method, n_stds=n_truncated_stds,
+                                                 horizontal_sweep=flag_det_horizontal, device=device)
+        else:
+            yaws, pitches = given_yaws, given_pitches
+        pos = sphere_positions(yaws, pitches, sphere_r)
+        cam2sphere = look_at_centre(pos).cpu().numpy()
     c2w = np.matmul(sphere_to_mpi_frame(sphere_center), cam2sphere)
     return c2w, yaws, pitches
 

@@ -50,3 +50,27 @@ for S, B in ((256, 8), (512, 4), (1024, 4)):
         tf, tfb = timeit(fwd), timeit(fwdbwd)
         print(f"{S}^2 x {D} planes, batch {B}, variant {variant:6s}: forward {tf:.3f} ms, forward+backward {tfb:.3f} ms "
               f"(backward ~{tfb - tf:.3f} ms = {B * S * S * D / (tfb - tf) / 1e3:.0f} Mpix*planes/s)")
+
+# ---- the shading augmentation in front of it (train.py:535-541): LightRenderer.render forward and forward+backward ----
+for S, B in ((256, 8), (512, 4), (1024, 4)):
+    D = 32
+    r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=D, device=dev, on_out_of_plane="raise")
+    L = ml_gmpi_amd.LightRenderer(sphere_center_z=1.0, sphere_r=1.0, ka_max=0.9, kd_max=0.1, n_grow_iters=1)
+    L.step = 10
+    vol = torch.rand((B, D, 4, S, S), device=dev)
+    vol[:, -1, 3] = 1.0
+    vol.requires_grad_(True)
+    xyz, _ = r.get_xyz(S, S, ret_single_res=True)
+    g = torch.randn((B, D, 4, S, S), device=dev)
+
+    def lfwd():
+        with torch.no_grad():
+            return L.render(vol.detach(), r.static_mpi_plane_dhws, xyz)
+
+    def lfwdbwd():
+        vol.grad = None
+        (L.render(vol, r.static_mpi_plane_dhws, xyz) * g).sum().backward()
+
+    tf, tfb = timeit(lfwd), timeit(lfwdbwd)
+    gb = B * D * S * S * 16 / 1e9
+    print(f"LightRenderer {S}^2 x {D} planes, batch {B}: forward {tf:.3f} ms, forward+backward {tfb:.3f} ms (volume {gb:.2f} GB fp32)")
