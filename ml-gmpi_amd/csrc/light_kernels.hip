@@ -114,30 +114,40 @@ static void launch_light_apply(const void* rgba, const int64_t* st, const float*
 // (1) out = clip(rgb * s, 0, 1) | alpha:   g_rgb = g_out * s * [0 < rgb*s < 1],  g_alpha = g_out_alpha (more is added by (2)),
 //     g_s[b,y,x] = sum_{k,c} g_out * rgb * [0 < rgb*s < 1].  One pixel column per thread, planes in a loop (coalesced in x).
 //     torch.clip passes the gradient at the bounds themselves (min <= x <= max), so the mask is closed.
-template <typename T>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void light_apply_backward_kernel(const T* __restrict__ rgba, int64_t sb, int64_t sd, int64_t sc,
                                                                    int64_t sr, const float* __restrict__ shading,
                                                                    const float* __restrict__ g_out, float* __restrict__ g_rgba,
                                                                    float* __restrict__ g_shading, int D, int H, int W) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * VEC, y = blockIdx.y, b = blockIdx.z;
     if (x >= W) return;
+    struct alignas(sizeof(T) * VEC) TV { T v[VEC]; };
+    struct alignas(sizeof(float) * VEC) FV { float v[VEC]; };
     const int64_t plane = static_cast<int64_t>(H) * W, pix = static_cast<int64_t>(y) * W + x;
-    const float s = shading[b * plane + pix];
-    float gs = 0.0f;
+    const FV s = *reinterpret_cast<const FV*>(shading + b * plane + pix);
+    FV gs;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) gs.v[i] = 0.0f;
     for (int k = 0; k < D; ++k) {
         const T* __restrict__ src = rgba + b * sb + k * sd + static_cast<int64_t>(y) * sr + x;
         const int64_t o = (static_cast<int64_t>(b) * D + k) * 4 * plane + pix;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = to_f32(src[c * sc]), g = g_out[o + c * plane];
-            const float t = v * s;
-            const bool pass = t >= 0.0f && t <= 1.0f;
-            g_rgba[o + c * plane] = pass ? g * s : 0.0f;
-            gs += pass ? g * v : 0.0f;
+            const TV v = *reinterpret_cast<const TV*>(src + c * sc);
+            const FV g = *reinterpret_cast<const FV*>(g_out + o + c * plane);
+            FV r;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float vf = to_f32(v.v[i]), t = vf * s.v[i];
+                const bool pass = t >= 0.0f && t <= 1.0f;
+                r.v[i] = pass ? g.v[i] * s.v[i] : 0.0f;
+                gs.v[i] += pass ? g.v[i] * vf : 0.0f;
+            }
+            *reinterpret_cast<FV*>(g_rgba + o + c * plane) = r;
         }
-        g_rgba[o + 3 * plane] = g_out[o + 3 * plane];
+        *reinterpret_cast<FV*>(g_rgba + o + 3 * plane) = *reinterpret_cast<const FV*>(g_out + o + 3 * plane);
     }
-    g_shading[b * plane + pix] = gs;
+    *reinterpret_cast<FV*>(g_shading + b * plane + pix) = gs;
 }
 
 // (2) depth = sum_k a_k T_k d_k (compute_depth): dL/da_k = g (T_k d_k - S_k / om_k), S_k = sum_{j>k} a_j T_j d_j, back to
@@ -229,12 +239,18 @@ int gmpi_light_apply_backward_launch(const void* rgba, int32_t rgba_dtype, const
     if (!rgba || !rgba_stride || !shading || !grad_out || !grad_rgba || !grad_shading) return GMPI_E_NULL;
     if (rgba_dtype < GMPI_DTYPE_F32 || rgba_dtype > GMPI_DTYPE_F16) return GMPI_E_DTYPE;
     if (rgba_stride[4] != 1 || rgba_stride[3] < W || rgba_stride[2] <= 0 || rgba_stride[1] <= 0 || rgba_stride[0] < 0) return GMPI_E_STRIDE;
-    const dim3 grid((W + 255) / 256, H, B), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t sb = rgba_stride[0], sd = rgba_stride[1], sc = rgba_stride[2], sr = rgba_stride[3];
-    if (rgba_dtype == GMPI_DTYPE_F32) hipLaunchKernelGGL(light_apply_backward_kernel<float>, grid, block, 0, st, static_cast<const float*>(rgba), sb, sd, sc, sr, shading, grad_out, grad_rgba, grad_shading, D, H, W);
-    else if (rgba_dtype == GMPI_DTYPE_BF16) hipLaunchKernelGGL(light_apply_backward_kernel<bf16_t>, grid, block, 0, st, static_cast<const bf16_t*>(rgba), sb, sd, sc, sr, shading, grad_out, grad_rgba, grad_shading, D, H, W);
-    else hipLaunchKernelGGL(light_apply_backward_kernel<f16_t>, grid, block, 0, st, static_cast<const f16_t*>(rgba), sb, sd, sc, sr, shading, grad_out, grad_rgba, grad_shading, D, H, W);
+    const int es = rgba_dtype == GMPI_DTYPE_F32 ? 4 : 2;
+    const bool vec = W % 4 == 0 && sb % 4 == 0 && sd % 4 == 0 && sc % 4 == 0 && sr % 4 == 0 && reinterpret_cast<uintptr_t>(rgba) % (4 * es) == 0 &&
+                     reinterpret_cast<uintptr_t>(shading) % 16 == 0 && reinterpret_cast<uintptr_t>(grad_out) % 16 == 0 &&
+                     reinterpret_cast<uintptr_t>(grad_rgba) % 16 == 0 && reinterpret_cast<uintptr_t>(grad_shading) % 16 == 0;
+    const dim3 block(256), grid(((vec ? W / 4 : W) + 255) / 256, H, B);
+#define GMPI_LAB(T, V) hipLaunchKernelGGL((light_apply_backward_kernel<T, V>), grid, block, 0, st, static_cast<const T*>(rgba), sb, sd, sc, sr, shading, grad_out, grad_rgba, grad_shading, D, H, W)
+    if (rgba_dtype == GMPI_DTYPE_F32) { if (vec) GMPI_LAB(float, 4); else GMPI_LAB(float, 1); }
+    else if (rgba_dtype == GMPI_DTYPE_BF16) { if (vec) GMPI_LAB(bf16_t, 4); else GMPI_LAB(bf16_t, 1); }
+    else { if (vec) GMPI_LAB(f16_t, 4); else GMPI_LAB(f16_t, 1); }
+#undef GMPI_LAB
     return rc_of(hipGetLastError());
 }
 
