@@ -108,3 +108,20 @@ def test_renderer_attributes_and_helpers():
     assert z.shape == (8, 1, 1, 1) and float(nz.min()) >= -1 - 1e-6 and float(nz.max()) <= 1 + 1e-6
     xyz, _ = r.get_xyz(16, 16)
     assert xyz.shape == (8, 16, 16, 3)
+
+
+def test_host_math_context_restores_the_intra_op_thread_count():
+    """poses.host_math(): tiny pose tensors run on one thread (the 128-thread pool of the GPU hosts makes them cost
+    milliseconds); the process-wide thread count is restored, nesting is a no-op, results do not depend on it."""
+    from ml_gmpi_amd import poses
+    before = torch.get_num_threads()
+    torch.manual_seed(4)
+    a = poses.truncated_normal(8, 0.0, 0.3, 2)
+    with poses.host_math():
+        inner = torch.get_num_threads()
+        with poses.host_math():
+            assert torch.get_num_threads() == 1
+        torch.manual_seed(4)
+        b = poses.truncated_normal(8, 0.0, 0.3, 2)
+    assert inner == 1 and torch.get_num_threads() == before
+    assert torch.equal(a, b)
