@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
-    ap.add_argument("--variant", default="auto", choices=["auto", "gather", "lds"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "gather", "lds", "wave"])
     ap.add_argument("--strict", action="store_true", help="strict-order arithmetic (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)

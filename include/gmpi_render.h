@@ -44,6 +44,7 @@ enum {
                                             variant is gmpi_rgba_range_check_launch                   */
     GMPI_FLAG_STRICT_ORDER = 1 << 4,     /* one rounding per reference op everywhere (bit-identical to
                                             oracle/mpi_oracle.c); default lets the blend use FMA       */
+    GMPI_FLAG_ALL = (1 << 5) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
 };
 
 /* bits of status[0] (OR-accumulated across launches until the caller clears the word) */
@@ -58,7 +59,8 @@ enum {
 enum {
     GMPI_VARIANT_AUTO = 0,
     GMPI_VARIANT_GATHER = 1, /* one pixel per lane, taps straight from global memory (any shape/stride) */
-    GMPI_VARIANT_LDS = 2     /* pixel tiles, texel boxes staged through LDS with 16-byte row loads      */
+    GMPI_VARIANT_LDS = 2,    /* pixel tiles, texel boxes staged through LDS with 16-byte row loads      */
+    GMPI_VARIANT_WAVE = 3    /* wave-private 32x8 pixel strips, fp32 RGBA boxes in LDS (the default)    */
 };
 
 enum {
@@ -69,6 +71,7 @@ enum {
     GMPI_E_STRIDE = -4,      /* innermost rgba stride != 1 or negative stride */
     GMPI_E_ABI = -5,         /* struct_size does not match this library       */
     GMPI_E_VARIANT = -6,     /* requested kernel variant cannot run this shape */
+    GMPI_E_FLAGS = -7,       /* a bit outside GMPI_FLAG_ALL is set            */
     GMPI_E_LAUNCH = -100     /* -100 - hipError_t of the failed launch        */
 };
 
@@ -210,7 +213,8 @@ int gmpi_alpha_depth_backward_launch(const void *alpha, int32_t alpha_dtype, int
                                      int64_t gstride_row, int32_t B, int32_t D, int32_t H, int32_t W, void *stream);
 
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
- * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height.  Unknown -> -1.      */
+ * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height, 6 whether
+ * GMPI_VARIANT_WAVE is built in.  Unknown -> -1.                                                */
 int gmpi_query(int32_t what);
 
 const char *gmpi_version_string(void);

@@ -17,8 +17,8 @@ DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 FLAG_ALIGN_CORNERS, FLAG_OUT_PM1, FLAG_CHECK_LAST_PLANE, FLAG_CHECK_RANGE, FLAG_STRICT_ORDER = 1, 2, 4, 8, 16
 STATUS_OUT_OF_LAST_PLANE, STATUS_RGBA_RANGE, STATUS_CAMERA_BEHIND_PLANE = 1, 2, 4
 STATUS_WORDS = 4
-VARIANT_AUTO, VARIANT_GATHER, VARIANT_LDS = 0, 1, 2
-VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS}
+VARIANT_AUTO, VARIANT_GATHER, VARIANT_LDS, VARIANT_WAVE = 0, 1, 2, 3
+VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS, "wave": VARIANT_WAVE}
 
 EXPORTS = (
     "gmpi_mpi_render_launch",
@@ -44,6 +44,7 @@ _ERRORS = {
     -4: "GMPI_E_STRIDE (innermost rgba stride must be 1, strides non-negative)",
     -5: "GMPI_E_ABI (GmpiRenderParams size mismatch between binding and library)",
     -6: "GMPI_E_VARIANT (requested kernel variant cannot run this shape)",
+    -7: "GMPI_E_FLAGS (undefined bit in GmpiRenderParams.flags)",
 }
 
 

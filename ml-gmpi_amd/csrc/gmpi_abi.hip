@@ -4,6 +4,8 @@
 
 #include "../../include/gmpi_render.h"
 
+#include <cstdlib>
+
 namespace gmpi {
 
 hipError_t launch_gather(const KParams& p, int dtype, hipStream_t stream);  // render_gather.hip
@@ -12,6 +14,8 @@ hipError_t launch_backward(const KParams& p, int dtype, const float* g_rgb, cons
                            const int64_t* gstride, bool tiles, hipStream_t stream);  // render_backward.hip
 bool lds_variant_supports(const KParams& p, int dtype);                     // render_lds.hip
 int lds_variant_query(int what);                                            // render_lds.hip
+hipError_t launch_wave(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_wave.hip
+bool wave_variant_supports(const KParams& p, int dtype);                    // render_wave.hip
 
 // ---- min/max of the normalised grid on the last plane (mpi.py:103-109 diagnostics) --------------
 template <bool AC>
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(256) void alpha_depth_kernel(const T* __restrict__ 
 static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, bool need_volume = false) {
     if (q == nullptr) return GMPI_E_NULL;
     if (q->struct_size != sizeof(GmpiRenderParams)) return GMPI_E_ABI;
+    if (q->flags & ~static_cast<uint32_t>(GMPI_FLAG_ALL)) return GMPI_E_FLAGS;  // undefined bits never reach a kernel
     if (q->N < 0 || q->M <= 0 || q->D <= 0 || q->Ht <= 0 || q->Wt <= 0 || q->H <= 0 || q->W <= 0) return GMPI_E_SHAPE;
     if (q->view_to_mpi == nullptr) {
         if (q->views_per_mpi < 1) return GMPI_E_SHAPE;
@@ -207,8 +212,19 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
     if (p.N == 0) return GMPI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int variant = params->variant;
-    if (variant == GMPI_VARIANT_AUTO) variant = lds_variant_supports(p, params->rgba_dtype) ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
+    if (variant == GMPI_VARIANT_AUTO)
+        variant = wave_variant_supports(p, params->rgba_dtype) ? GMPI_VARIANT_WAVE
+                  : lds_variant_supports(p, params->rgba_dtype) ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
     if (variant == GMPI_VARIANT_GATHER) return hip_rc(launch_gather(p, params->rgba_dtype, st));
+    if (variant == GMPI_VARIANT_WAVE) {
+        if (!wave_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
+        int tune = 0;
+#ifdef GMPI_TUNE
+        static const int env_tune = [] { const char* e = getenv("GMPI_TUNE_WAVE"); return e ? atoi(e) : 0; }();
+        tune = env_tune;
+#endif
+        return hip_rc(launch_wave(p, params->rgba_dtype, tune, st));
+    }
     if (variant == GMPI_VARIANT_LDS) {
         if (!lds_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
         return hip_rc(launch_lds(p, params->rgba_dtype, st));
@@ -320,6 +336,7 @@ int gmpi_query(int32_t what) {
         case 1: return static_cast<int>(sizeof(GmpiRenderParams));
         case 2: return 950;
         case 3: case 4: case 5: return lds_variant_query(what);
+        case 6: return 1;  // GMPI_VARIANT_WAVE is built in
         default: return -1;
     }
 }

@@ -33,7 +33,7 @@ class MPI(nn.Module):
     """Drop-in for `gmpi.core.mpi.MPI`.
 
     Extra constructor knobs (all optional; defaults reproduce the reference's behaviour):
-      variant        "auto" | "gather" | "lds"  -- kernel selection (GMPI_VARIANT_*)
+      variant        "auto" | "gather" | "lds" | "wave"  -- kernel selection (GMPI_VARIANT_*)
       strict_order   one rounding per reference op also in the blend (bit-identical to the oracle)
       range_check    "touched" (default: alpha/rgba range asserted on the texels the render samples, free),
                      "full" (extra exhaustive pass = the reference's min/max over the whole volume), "off"

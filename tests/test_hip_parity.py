@@ -27,7 +27,7 @@ def _lib():
 def variants():
     L = _lib()
     lib = L.load_library()
-    return ["gather", "lds"] if lib.gmpi_query(3) > 0 else ["gather"]
+    return ["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
 
 
 def hip_render(rgba, dhw, ray_dir, eye, zdir, *, ac=True, variant="gather", strict=False, view_to_mpi=None,
@@ -50,7 +50,7 @@ def hip_render(rgba, dhw, ray_dir, eye, zdir, *, ac=True, variant="gather", stri
         except GmpiError as e:
             # shapes the LDS kernel cannot stage (texture width not a multiple of 4, unaligned strides) must be
             # refused when forced and handled by "auto" (which then picks the gather kernel)
-            if variant != "lds" or "GMPI_E_VARIANT" not in str(e):
+            if variant not in ("lds", "wave") or "GMPI_E_VARIANT" not in str(e):
                 raise
             mpi.variant = "auto"
             out = mpi.render_views(*args, **kw)

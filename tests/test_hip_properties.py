@@ -22,7 +22,8 @@ DEV = "cuda:0"
 
 def variants():
     from ml_gmpi_amd import _lib as L
-    return ["gather", "lds"] if L.load_library().gmpi_query(3) > 0 else ["gather"]
+    lib = L.load_library()
+    return ["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
 
 
 def setup(S, D, B, preset="FFHQ", dtype=torch.float32, seed=0, last_alpha_one=False, extreme=False):
