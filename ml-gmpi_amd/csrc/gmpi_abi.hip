@@ -9,7 +9,7 @@
 namespace gmpi {
 
 hipError_t launch_gather(const KParams& p, int dtype, hipStream_t stream);  // render_gather.hip
-hipError_t launch_lds(const KParams& p, int dtype, hipStream_t stream);     // render_lds.hip
+hipError_t launch_lds(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_lds.hip
 hipError_t launch_backward(const KParams& p, int dtype, const float* g_rgb, const float* g_depth, float* g_rgba,
                            const int64_t* gstride, bool tiles, hipStream_t stream);  // render_backward.hip
 bool lds_variant_supports(const KParams& p, int dtype);                     // render_lds.hip
@@ -212,22 +212,27 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
     if (p.N == 0) return GMPI_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int variant = params->variant;
-    if (variant == GMPI_VARIANT_AUTO)
-        variant = wave_variant_supports(p, params->rgba_dtype) ? GMPI_VARIANT_WAVE
-                  : lds_variant_supports(p, params->rgba_dtype) ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
+    if (variant == GMPI_VARIANT_AUTO) {
+        // Measured on MI355X (profiles/r02_variants.txt): the tile kernel wins on large launches (C3-C5: 32 waves per CU hide
+        // its latencies, its shared 32x16 boxes tolerate tilted cameras); the strip kernel wins when the launch under-fills
+        // the chip (C2: 8 views of 256^2 = 2 K pixels per CU: 4 pixels per lane need a quarter of the waves)
+        const int64_t pixels = static_cast<int64_t>(p.N) * p.H * p.W;
+        const bool lds_ok = lds_variant_supports(p, params->rgba_dtype), wave_ok = wave_variant_supports(p, params->rgba_dtype);
+        variant = (wave_ok && (pixels <= (int64_t(1) << 20) || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
+    }
     if (variant == GMPI_VARIANT_GATHER) return hip_rc(launch_gather(p, params->rgba_dtype, st));
+    int tune = 0;
+#ifdef GMPI_TUNE  // profiling builds only (make EXTRA=-DGMPI_TUNE): experiment knobs from the environment
+    static const int env_tune = [] { const char* e = getenv("GMPI_TUNE_WAVE"); return e ? atoi(e) : 0; }();
+    tune = env_tune;
+#endif
     if (variant == GMPI_VARIANT_WAVE) {
         if (!wave_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
-        int tune = 0;
-#ifdef GMPI_TUNE
-        static const int env_tune = [] { const char* e = getenv("GMPI_TUNE_WAVE"); return e ? atoi(e) : 0; }();
-        tune = env_tune;
-#endif
         return hip_rc(launch_wave(p, params->rgba_dtype, tune, st));
     }
     if (variant == GMPI_VARIANT_LDS) {
         if (!lds_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
-        return hip_rc(launch_lds(p, params->rgba_dtype, st));
+        return hip_rc(launch_lds(p, params->rgba_dtype, tune, st));
     }
     return GMPI_E_VARIANT;
 }

@@ -202,6 +202,7 @@ __device__ __forceinline__ void blend(Accum& A, float r, float g, float b, float
         A.g = __builtin_fmaf(w, g, A.g);
         A.b = __builtin_fmaf(w, b, A.b);
         A.z = __builtin_fmaf(w, s, A.z);
+        // (T - a*T would save an instruction but cancels behind nearly opaque planes: 1 - a is exact, a*T is not)
         float om = 1.0f - a;
         om = om + 1e-10f;
         A.T = A.T * om;
@@ -240,6 +241,13 @@ __device__ __forceinline__ void gather_sample(const TexT* __restrict__ pl, int64
         if (check_range && !(in_unit(t_nw) && in_unit(t_ne) && in_unit(t_sw) && in_unit(t_se))) bad |= 2u;
         smp[c] = bilerp<STRICT>(t_nw, t_ne, t_sw, t_se, f);
     }
+}
+
+// floor(x) as an integer in one instruction (v_cvt_flr_i32_f32); NaN -> 0, saturating
+__device__ __forceinline__ int floor_to_int(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 // OR a per-lane flag word into status[0] with at most one atomic per wave.

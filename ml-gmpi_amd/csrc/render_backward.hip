@@ -264,7 +264,9 @@ __global__ __launch_bounds__(kBwdThreads, 6) void render_backward_tile_kernel(co
                     for (int c = 0; c < 4; ++c) {
                         const float d = d_s[c];
                         unsigned long long* __restrict__ lc = l0 + c * kBwdPitch;
+#ifdef GMPI_TUNE
                         if (p.flags & (1u << 21)) continue;
+#endif
                         if (x0in && y0in) atomicAdd(lc, fix(d * f.nw));
                         if (x1in && y0in) atomicAdd(lc + 1, fix(d * f.ne));
                         if (x0in && y1in) atomicAdd(lc + 4 * kBwdPitch, fix(d * f.sw));
@@ -321,9 +323,11 @@ static hipError_t launch_backward_t(const KParams& p, const BwdParams& b, bool t
 // (GMPI_VARIANT_GATHER: the simple kernel, kept as the cross-check)
 hipError_t launch_backward(const KParams& p0, int dtype, const float* g_rgb, const float* g_depth, float* g_rgba,
                            const int64_t* gstride, bool tiles, hipStream_t stream) {
-    static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     KParams p = p0;
-    p.flags |= skip << 16;  // profiling experiments only: 16 = no global atomics in the flush, 32 = no LDS atomics
+#ifdef GMPI_TUNE  // profiling builds only: 16 = no global atomics in the flush, 32 = no LDS atomics
+    static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
+    p.flags |= skip << 16;
+#endif
     BwdParams b;
     b.g_rgb = g_rgb, b.g_depth = g_depth, b.g_rgba = g_rgba;
     b.gs_mpi = gstride[0], b.gs_plane = gstride[1], b.gs_chan = gstride[2], b.gs_row = gstride[3];

@@ -40,7 +40,6 @@
 // of tiles).  Algorithmic bytes: 16 B (fp32) / 8 B (bf16) per pixel*plane + 28-32 B per pixel.
 #include "gmpi_device.hpp"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace gmpi {
@@ -62,7 +61,7 @@ template <int TW> struct TileCfg;
 template <> struct TileCfg<32> { static constexpr int kPitch = 56, kMaxLines = 108; };
 template <> struct TileCfg<64> { static constexpr int kPitch = 96, kMaxLines = 56; };
 template <int TW> constexpr int lds_bytes() { return kChunk * kRecBytes + 2 * TileCfg<TW>::kMaxLines * TileCfg<TW>::kPitch * 4; }
-static_assert(lds_bytes<32>() <= 53 * 1024 && lds_bytes<64>() <= 53 * 1024, "3 workgroups per CU");
+static_assert(lds_bytes<32>() <= 53 * 1024, "3 workgroups per CU");
 
 // Loader geometry: one item = 16 bytes of storage = TPI texels; a box line holds kPitch/TPI items.
 // (LPR = lines per texel row: 4 (row,channel) lines in the planar layout, 1 in the texel-interleaved one)
@@ -323,7 +322,11 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         // One buffer resource per plane (its 4 channel images); items that fall outside the box or outside the
         // texture get the offset 0x80000000, which the hardware range check turns into zeros without touching
         // memory -- no exec masking, loads issue back to back and stay two planes ahead.
+#ifdef GMPI_TUNE
         const int load_mask = (p.flags & (1u << 16)) ? 0 : 0xff, store_mask = (p.flags & (1u << 18)) ? 0 : 0xff;  // ablation bits
+#else
+        constexpr int load_mask = 0xff, store_mask = 0xff;
+#endif
         const int chan_bytes = __builtin_amdgcn_readfirstlane(static_cast<int>(s_chan * static_cast<int64_t>(sizeof(TexT))));
         // (predicates are combined with bitwise ops on purpose: `&&` would be lowered to exec-mask control flow)
         auto issue_loads = [&](auto np, int t, u32x4 (&L)[decltype(np)::value], bool (&in_box)[decltype(np)::value]) {
@@ -448,7 +451,10 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         };
 
         auto composite = [&](int t, const float* __restrict__ tile, bool mine) {
-            if (t >= kn || (p.flags & (1u << 17))) return;  // workgroup-uniform: padding plane / ablation
+#ifdef GMPI_TUNE
+            if (p.flags & (1u << 17)) return;  // ablation: no compositing
+#endif
+            if (t >= kn) return;  // workgroup-uniform: padding plane
             if (!mine) return;
             const float4 rf = tabF[t];
             const int4 rg = tabG[t];
@@ -461,14 +467,14 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             } else {
                 plane_coord_recip<AC>(rf.x, rf.y, rf.z, rf.w, __int_as_float(rg.x), ex, ey, rx, ry, rz, rcp_rz, cx,
                                       cy, ix, iy, s);
-                // ATen's vectorised CPU form of the weights: e = 1 - w (equals x1 - ix unless ix < 0)
-                const float wx1 = ix - floorf(ix), wy1 = iy - floorf(iy);
+                // ATen's vectorised CPU form of the weights: e = 1 - w (equals x1 - ix unless ix < 0); v_fract_f32 = ix - floor(ix)
+                const float wx1 = __builtin_amdgcn_fractf(ix), wy1 = __builtin_amdgcn_fractf(iy);
                 const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
                 f.nw = wx0 * wy0, f.ne = wx1 * wy0, f.sw = wx0 * wy1, f.se = wx1 * wy1;
             }
             // the box contains every tap of the tile (corner argument above); the integer corner is taken from the
             // floor directly (Footprint::x0/y0 carry the gather path's out-of-range sentinel)
-            const int lx = static_cast<int>(floorf(ix)) - rg.y, ly = static_cast<int>(floorf(iy)) - rg.z;
+            const int lx = (STRICT ? static_cast<int>(floorf(ix)) : floor_to_int(ix)) - rg.y, ly = (STRICT ? static_cast<int>(floorf(iy)) : floor_to_int(iy)) - rg.z;
             // unsigned + clamped: keeps wild coordinates (NaN rays) inside the buffer and proves the base non-negative,
             // so the 8 tap-pair reads become ds_read2_b32 with immediate offsets
             float smp[4];
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
             const bool unfit = build_table(y_lo, y_hi);
             if (h < 0 && unfit) continue;          // try the halves
             const bool mine = h < 0 || half == h;
-            if (!unfit) set_loader_map((p.flags & (1u << 19)) ? kCols : max_nq, (p.flags & (1u << 19)) ? kMaxRows : max_rows);
+            if (!unfit) set_loader_map(max_nq, max_rows);
             // the pass count is a compile-time constant of the plane loop (a run-time trip count makes hipcc wait for
             // the prefetch, vmcnt(0), before compositing): one instance per count, selected per chunk
             if (!unfit) {
@@ -637,37 +643,15 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int TW, int MINW, int PF>
-static hipError_t launch_lds_w(const KParams& p, int dtype, int layout, int layout32, hipStream_t stream) {
+hipError_t launch_lds(const KParams& p, int dtype, int tune, hipStream_t stream) {
+    // Shipped instances only: fp32 volumes keep fp32 planes in LDS (LAYOUT 0, 3 workgroups per CU), 16-bit volumes their raw
+    // texels, interleaved (LAYOUT 1, 4 workgroups per CU); 32x16 pixel tiles, one plane of prefetch -- the values the round-1
+    // ablations settled on (profiles/r01_ablation.txt; the other combinations are no longer instantiated).
+    (void)tune;
     switch (dtype) {
-        case 0: return layout32 == 1 ? launch_lds_t<float, TW, MINW, PF, 1>(p, stream) : launch_lds_t<float, TW, MINW, PF, 0>(p, stream);
-        case 1: return layout == 1 ? launch_lds_t<bf16_t, TW, MINW, PF, 1>(p, stream) : launch_lds_t<bf16_t, TW, MINW, PF, 0>(p, stream);
-        default: return layout == 1 ? launch_lds_t<f16_t, TW, MINW, PF, 1>(p, stream) : launch_lds_t<f16_t, TW, MINW, PF, 0>(p, stream);
-    }
-}
-
-hipError_t launch_lds(const KParams& p0, int dtype, hipStream_t stream) {
-    // experiment knobs (environment): GMPI_TUNE_PF 1|2|3 = planes of prefetch, GMPI_TUNE_TW 32|64 = tile width,
-    // GMPI_TUNE_LAYOUT / GMPI_TUNE_LAYOUT32 0|1 = LDS layout of 16-bit / fp32 volumes (fp32 planes | raw interleaved texels),
-    // GMPI_TUNE_SKIP = ablation bits (see flags bits 16-19)
-    static const int pf = [] { const char* e = getenv("GMPI_TUNE_PF"); return e ? atoi(e) : 1; }();
-    static const int tw = [] { const char* e = getenv("GMPI_TUNE_TW"); return e ? atoi(e) : kTileW; }();
-    static const int layout = [] { const char* e = getenv("GMPI_TUNE_LAYOUT"); return e ? atoi(e) : kLayout16; }();
-    static const int layout32 = [] { const char* e = getenv("GMPI_TUNE_LAYOUT32"); return e ? atoi(e) : kLayout32; }();
-    // waves/SIMD the register allocator targets for 16-bit volumes in the interleaved layout (29 KB of LDS per workgroup:
-    // 4 workgroups per CU at 64 VGPRs; the spills stay outside the plane loop; +3.5 % over 6 waves/SIMD, r01_ablation.txt)
-    static const int minw = [] { const char* e = getenv("GMPI_TUNE_MINW"); return e ? atoi(e) : 8; }();
-    static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
-    KParams p = p0;
-    p.flags |= skip << 16;  // profiling experiments only: 1 = no global loads, 2 = no compositing, 4 = no LDS stores, 8 = static loader map
-    if (tw == 64) return launch_lds_w<64, 6, 1>(p, dtype, 0, 0, stream);
-    switch (pf) {
-        case 2: return launch_lds_w<32, 6, 2>(p, dtype, 0, 0, stream);
-        case 3: return launch_lds_w<32, 6, 3>(p, dtype, 0, 0, stream);
-        default:
-            if (minw == 8 && dtype != 0 && layout == 1)
-                return dtype == 1 ? launch_lds_t<bf16_t, 32, 8, 1, 1>(p, stream) : launch_lds_t<f16_t, 32, 8, 1, 1>(p, stream);
-            return launch_lds_w<32, 6, 1>(p, dtype, layout, layout32, stream);
+        case 0: return launch_lds_t<float, kTileW, 6, 1, 0>(p, stream);
+        case 1: return launch_lds_t<bf16_t, kTileW, 8, 1, 1>(p, stream);
+        default: return launch_lds_t<f16_t, kTileW, 8, 1, 1>(p, stream);
     }
 }
 
