@@ -51,7 +51,8 @@ enum {
 enum {
     GMPI_STATUS_OUT_OF_LAST_PLANE = 1u << 0, /* mpi.py:106-109 would have failed                      */
     GMPI_STATUS_RGBA_RANGE = 1u << 1,        /* mpi.py:185-187 / mpi_renderer.py:447-449              */
-    GMPI_STATUS_CAMERA_BEHIND_PLANE = 1u << 2 /* mpi.py:70-72 "Camera must be placed closer..."      */
+    GMPI_STATUS_CAMERA_BEHIND_PLANE = 1u << 2, /* mpi.py:70-72 "Camera must be placed closer..."     */
+    GMPI_STATUS_BAD_VIEW_INDEX = 1u << 3      /* view_to_mpi[n] outside [0, M): clamped and reported   */
 };
 #define GMPI_STATUS_WORDS 4
 
@@ -66,7 +67,8 @@ enum {
 enum {
     GMPI_OK = 0,
     GMPI_E_NULL = -1,        /* required pointer is NULL                      */
-    GMPI_E_SHAPE = -2,       /* non-positive / inconsistent extent            */
+    GMPI_E_SHAPE = -2,       /* non-positive / inconsistent extent; N > 65535 views for the gather kernel
+                                or the backward (split the batch)             */
     GMPI_E_DTYPE = -3,       /* unknown rgba_dtype                            */
     GMPI_E_STRIDE = -4,      /* innermost rgba stride != 1 or negative stride */
     GMPI_E_ABI = -5,         /* struct_size does not match this library       */
@@ -211,6 +213,15 @@ int gmpi_alpha_depth_backward_launch(const void *alpha, int32_t alpha_dtype, int
                                      int64_t stride_row, const float *plane_ds, const float *transmittance,
                                      const float *grad_depth, float *grad_alpha, int64_t gstride_b, int64_t gstride_d,
                                      int64_t gstride_row, int32_t B, int32_t D, int32_t H, int32_t W, void *stream);
+
+/*
+ * Self-test of the default mode's division: the coordinate chain (mpi.py:76, 89-90) divides through correctly rounded
+ * reciprocals hoisted out of the plane loop (q0 = n*r, e = fma(-d, q0, n), q = fma(e, r, q0) with r = RN(1/d)); this entry
+ * compares that against the IEEE division on `pairs` pseudo-random operand pairs (classes: 0 zdiff/ray_z, 1 x/(w/2),
+ * 2 full-range significands with exponents within +-20, 3 divisors 2^k (2 - 2^-23)) and ADDS the number of pairs whose
+ * quotients differ in any bit to mismatches[class] (device memory, 4 x uint64, zero-filled by the caller).
+ */
+int gmpi_selftest_division_launch(uint64_t pairs, uint32_t seed, uint64_t *mismatches, void *stream);
 
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
  * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height, 6 whether

@@ -15,7 +15,7 @@ _LIB = None
 ABI_VERSION = 1
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 FLAG_ALIGN_CORNERS, FLAG_OUT_PM1, FLAG_CHECK_LAST_PLANE, FLAG_CHECK_RANGE, FLAG_STRICT_ORDER = 1, 2, 4, 8, 16
-STATUS_OUT_OF_LAST_PLANE, STATUS_RGBA_RANGE, STATUS_CAMERA_BEHIND_PLANE = 1, 2, 4
+STATUS_OUT_OF_LAST_PLANE, STATUS_RGBA_RANGE, STATUS_CAMERA_BEHIND_PLANE, STATUS_BAD_VIEW_INDEX = 1, 2, 4, 8
 STATUS_WORDS = 4
 VARIANT_AUTO, VARIANT_GATHER, VARIANT_LDS, VARIANT_WAVE = 0, 1, 2, 3
 VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS, "wave": VARIANT_WAVE}
@@ -33,13 +33,14 @@ EXPORTS = (
     "gmpi_light_apply_launch",
     "gmpi_light_apply_backward_launch",
     "gmpi_alpha_depth_backward_launch",
+    "gmpi_selftest_division_launch",
     "gmpi_query",
     "gmpi_version_string",
 )
 
 _ERRORS = {
     -1: "GMPI_E_NULL (required pointer is NULL)",
-    -2: "GMPI_E_SHAPE (non-positive or inconsistent extent)",
+    -2: "GMPI_E_SHAPE (non-positive or inconsistent extent, or more than 65535 views for the gather kernel / the backward)",
     -3: "GMPI_E_DTYPE (unknown rgba dtype)",
     -4: "GMPI_E_STRIDE (innermost rgba stride must be 1, strides non-negative)",
     -5: "GMPI_E_ABI (GmpiRenderParams size mismatch between binding and library)",
@@ -134,6 +135,8 @@ def load_library():
     lib.gmpi_alpha_depth_backward_launch.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, vp,
                                                      vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    lib.gmpi_selftest_division_launch.restype = ctypes.c_int
+    lib.gmpi_selftest_division_launch.argtypes = [ctypes.c_uint64, ctypes.c_uint32, vp, vp]
     lib.gmpi_query.restype = ctypes.c_int
     lib.gmpi_query.argtypes = [ctypes.c_int32]
     lib.gmpi_version_string.restype = ctypes.c_char_p

@@ -21,7 +21,8 @@ bool wave_variant_supports(const KParams& p, int dtype);                    // r
 template <bool AC>
 __global__ __launch_bounds__(256) void last_plane_uv_kernel(const KParams p, float* __restrict__ uv) {
     const int n = blockIdx.x;
-    const int m = p.view_to_mpi ? p.view_to_mpi[n] : n / p.views_per_mpi;
+    uint32_t bad_index = 0;  // (the forward reports a bad view index; here it is only clamped)
+    const int m = view_mpi(p, n, bad_index);
     const float* dhw = p.dhw + (static_cast<int64_t>(m) * p.D + (p.D - 1)) * 3;
     const float d = dhw[0], ph = dhw[1], pw = dhw[2];
     const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
@@ -157,6 +158,51 @@ __global__ __launch_bounds__(256) void alpha_depth_kernel(const T* __restrict__ 
     if (tout) tout[o] = Tr;
 }
 
+// ---- self-test of div_by_recip (gmpi_device.hpp): q = n / d through RN(1/d) against the IEEE division --------------
+// Operand classes: 0 = zdiff / ray_z (plane distance minus eye height over the z component of a unit ray), 1 = x / (w/2)
+// (in-plane position over a plane half extent), 2 = full-range significands and exponents within +-20, 3 = divisors of the
+// one significand pattern the correction step's proof treats separately, d = 2^k (2 - 2^-23).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {  // lowbias32
+    x ^= x >> 16, x *= 0x7feb352du, x ^= x >> 15, x *= 0x846ca68bu, x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float unit_float(uint32_t h) { return __uint_as_float(0x3f800000u | (h >> 9)) - 1.0f; }  // [0, 1)
+__global__ __launch_bounds__(256) void selftest_division_kernel(uint64_t pairs, uint32_t seed, unsigned long long* mism) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned int bad[4] = {0, 0, 0, 0};
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+        const uint32_t lo = static_cast<uint32_t>(i), hi = static_cast<uint32_t>(i >> 32);
+        const uint32_t a = mix32(lo ^ seed), b = mix32(a + hi * 0x9e3779b9u + 0x85ebca6bu), c = mix32(b ^ 0xc2b2ae35u);
+        const int cls = static_cast<int>(c & 3u);
+        float n, d;
+        if (cls == 0) {
+            n = (unit_float(a) - 0.5f) * 4.0f;             // zdiff in [-2, 2)
+            d = 0.35f + 0.65f * unit_float(b);             // ray_z of a unit ray inside a < 70 degree cone
+            if (c & 4u) d = -d;
+        } else if (cls == 1) {
+            n = (unit_float(a) - 0.5f) * 2.0f;             // x in [-1, 1)
+            d = 0.02f + 2.0f * unit_float(b);              // half extent of a plane
+        } else if (cls == 2) {
+            n = __uint_as_float((a & 0x807fffffu) | ((107u + (a >> 23) % 41u) << 23));   // exponent in [-20, 20]
+            d = __uint_as_float((b & 0x807fffffu) | ((107u + (b >> 23) % 41u) << 23));
+        } else {
+            n = __uint_as_float((a & 0x807fffffu) | ((107u + (a >> 23) % 41u) << 23));
+            d = __uint_as_float(0x007fffffu | ((107u + (b >> 23) % 41u) << 23) | (b & 0x80000000u));  // 2^k (2 - 2^-23)
+        }
+        const float r = 1.0f / d;
+        const float q = div_by_recip(n, d, r);
+        const float q_ref = n / d;
+        if (__float_as_uint(q) != __float_as_uint(q_ref) && !(q == 0.0f && q_ref == 0.0f)) bad[cls]++;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned int v = bad[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(mism + k, static_cast<unsigned long long>(v));
+    }
+}
+
 static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, bool need_volume = false) {
     if (q == nullptr) return GMPI_E_NULL;
     if (q->struct_size != sizeof(GmpiRenderParams)) return GMPI_E_ABI;
@@ -220,7 +266,10 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         const bool lds_ok = lds_variant_supports(p, params->rgba_dtype), wave_ok = wave_variant_supports(p, params->rgba_dtype);
         variant = (wave_ok && (pixels <= (int64_t(1) << 20) || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
     }
-    if (variant == GMPI_VARIANT_GATHER) return hip_rc(launch_gather(p, params->rgba_dtype, st));
+    if (variant == GMPI_VARIANT_GATHER) {
+        if (p.N > 65535) return GMPI_E_SHAPE;  // the gather kernel puts the view index in grid.z
+        return hip_rc(launch_gather(p, params->rgba_dtype, st));
+    }
     int tune = 0;
 #ifdef GMPI_TUNE  // profiling builds only (make EXTRA=-DGMPI_TUNE): experiment knobs from the environment
     static const int env_tune = [] { const char* e = getenv("GMPI_TUNE_WAVE"); return e ? atoi(e) : 0; }();
@@ -244,6 +293,7 @@ int gmpi_mpi_render_backward_launch(const GmpiRenderParams* params, const float*
     const int rc = to_kparams(params, p, false, true);
     if (rc != GMPI_OK) return rc;
     if (grad_rgb == nullptr || grad_rgba == nullptr || grad_rgba_stride == nullptr) return GMPI_E_NULL;
+    if (p.N > 65535) return GMPI_E_SHAPE;  // both backward kernels put the view index in grid.y / grid.z: split the batch
     if (grad_rgba_stride[4] != 1) return GMPI_E_STRIDE;
     for (int i = 0; i < 4; ++i)
         if (grad_rgba_stride[i] <= 0 && !(i == 0 && params->M == 1)) return GMPI_E_STRIDE;
@@ -332,6 +382,16 @@ int gmpi_alpha_depth_launch(const void* alpha, int32_t alpha_dtype, int64_t stri
         hipLaunchKernelGGL(alpha_depth_kernel<bf16_t>, grid, block, 0, st, static_cast<const bf16_t*>(alpha), stride_b, stride_d, stride_row, plane_ds, D, H, W, depth_out, transmittance_out);
     else
         hipLaunchKernelGGL(alpha_depth_kernel<f16_t>, grid, block, 0, st, static_cast<const f16_t*>(alpha), stride_b, stride_d, stride_row, plane_ds, D, H, W, depth_out, transmittance_out);
+    return hip_rc(hipGetLastError());
+}
+
+int gmpi_selftest_division_launch(uint64_t pairs, uint32_t seed, uint64_t* mismatches, void* stream) {
+    if (mismatches == nullptr) return GMPI_E_NULL;
+    if (pairs == 0) return GMPI_OK;
+    const uint64_t want = (pairs + 255) / 256;
+    const unsigned blocks = static_cast<unsigned>(want < 256u * 64u ? want : 256u * 64u);
+    hipLaunchKernelGGL(selftest_division_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), pairs, seed,
+                       reinterpret_cast<unsigned long long*>(mismatches));
     return hip_rc(hipGetLastError());
 }
 

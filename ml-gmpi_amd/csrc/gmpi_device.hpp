@@ -36,6 +36,17 @@ struct KParams {
     uint32_t flags;
 };
 
+// MPI sampled by view n: view_to_mpi[n], or n / views_per_mpi.  An index outside [0, M) would address dhw and the volume
+// out of bounds: it is clamped and reported (status bit 8 = GMPI_STATUS_BAD_VIEW_INDEX) instead.
+__device__ __forceinline__ int view_mpi(const KParams& p, int n, uint32_t& bad) {
+    int m = p.view_to_mpi ? p.view_to_mpi[n] : n / p.views_per_mpi;
+    if (m < 0 || m >= p.M) {
+        bad |= 8u;
+        m = min(max(m, 0), p.M - 1);
+    }
+    return m;
+}
+
 // ---- texel fetch: storage type -> fp32 (exact upcast, mpi_renderer.py:446) -----------------------
 struct bf16_t { uint16_t bits; };
 struct f16_t { _Float16 v; };
@@ -91,10 +102,11 @@ __device__ __forceinline__ void plane_coord(float zdiff, float ph, float pw, flo
 // n/d, the corrected quotient is the correctly rounded one (for normal-range operands and results;
 // the single exceptional significand pattern d = 2^k*(2-2^-23) needs n*r to be faithful, which it
 // is here).  r is an IEEE division itself (1.0f / d) but a loop-invariant one: per pixel for ray_z,
-// per plane for the plane extents.  `gmpi_selftest_division` (C ABI) compares this against the
-// hardware-correct `/` on 2^32 operand pairs drawn from the renderer's ranges and on the edge
-// patterns; tests/test_hip_parity.py runs it, and the strict-order mode (compiler division) is
-// bit-identical to the oracle, so any slip would surface as a parity failure.
+// per plane for the plane extents.  `gmpi_selftest_division_launch` (C ABI, gmpi_abi.hip) compares this
+// against the hardware-correct `/` on 2^32 operand pairs drawn from the renderer's ranges and on the edge
+// pattern (tests/test_hip_parity.py::test_division_through_reciprocal_is_exact runs it), and
+// tests/test_hip_parity.py::test_default_mode_samples_the_strict_texels checks the texel indices of the
+// default mode against the strict-order mode (compiler division) on fuzzed poses.
 __device__ __forceinline__ float div_by_recip(float n, float d, float r) {
     const float q0 = n * r;
     const float e = __builtin_fmaf(-d, q0, n);

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void render_backward_kernel(const KParams p, c
     const int px = blockIdx.x * 64 + threadIdx.x;
     const int py = blockIdx.y * 4 + threadIdx.y;
     if (px >= p.W || py >= p.H) return;
-    const int m = p.view_to_mpi ? p.view_to_mpi[n] : n / p.views_per_mpi;
+    uint32_t bad_index = 0;  // (the forward reports a bad view index; here it is only clamped)
+    const int m = view_mpi(p, n, bad_index);
     const float* __restrict__ dhw = p.dhw + static_cast<int64_t>(m) * p.D * 3;
     const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
     const int64_t HW = static_cast<int64_t>(p.H) * p.W;
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(kBwdThreads, 6) void render_backward_tile_kernel(co
     const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
     const int px = txi * kBwdTW + (tid % kBwdTW), py = tyi * kBwdTH + (tid / kBwdTW);
     const bool active = px < p.W && py < p.H;
-    const int m = p.view_to_mpi ? p.view_to_mpi[n] : n / p.views_per_mpi;
+    uint32_t bad_index = 0;  // (the forward reports a bad view index; here it is only clamped)
+    const int m = view_mpi(p, n, bad_index);
     const float* __restrict__ dhw = p.dhw + static_cast<int64_t>(m) * p.D * 3;
     const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
     const int64_t HW = static_cast<int64_t>(p.H) * p.W;

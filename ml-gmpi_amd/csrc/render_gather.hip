@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kGatherTileW* kGatherTileH) void render_gather_kern
     const int n = blockIdx.z;
     const int px = blockIdx.x * kGatherTileW + threadIdx.x;
     const int py = blockIdx.y * kGatherTileH + threadIdx.y;
-    const int m = p.view_to_mpi ? p.view_to_mpi[n] : n / p.views_per_mpi;
+    uint32_t bad = 0;
+    const int m = view_mpi(p, n, bad);  // (an index outside [0, M) is clamped and reported)
 
     const float* __restrict__ dhw = p.dhw + static_cast<int64_t>(m) * p.D * 3;
     const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
@@ -52,7 +53,6 @@ __global__ __launch_bounds__(kGatherTileW* kGatherTileH) void render_gather_kern
     const int64_t s_chan = p.s_chan, s_row = p.s_row;
 
     Accum A;
-    uint32_t bad = 0;
 #pragma unroll 2
     for (int k = 0; k < p.D; ++k) {
         const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
     }
     const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
 
-    const int m = p.view_to_mpi ? p.view_to_mpi[n] : n / p.views_per_mpi;
+    uint32_t bad = 0;
+    const int m = view_mpi(p, n, bad);  // (an index outside [0, M) is clamped and reported)
     const int D = p.D, Ht = p.Ht, Wt = p.Wt, H = p.H, W = p.W;
     const float* __restrict__ dhw = p.dhw + static_cast<int64_t>(m) * D * 3;
     const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
@@ -153,7 +154,6 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
     const TexT* __restrict__ vol = static_cast<const TexT*>(p.rgba) + static_cast<int64_t>(m) * p.s_mpi;
     const int64_t s_chan = p.s_chan, s_row = p.s_row, s_plane = p.s_plane;
 
-    uint32_t bad = 0;
     if (p.status != nullptr && trem == 0 && threadIdx.x == 0) {  // mpi.py:70-72, once per view
         const float ez0 = p.eye_pos[2];
         bool behind = false;

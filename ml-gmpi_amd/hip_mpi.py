@@ -10,6 +10,7 @@ folded into a status bit), no min/max passes (mpi.py:185-187).
 There is no CPU/PyTorch fallback: tensors must live on a ROCm device and the HIP library must be
 built, otherwise this raises.
 """
+import contextlib
 import ctypes
 import sys
 from typing import List, Optional, Sequence, Union
@@ -35,15 +36,23 @@ class MPI(nn.Module):
     Extra constructor knobs (all optional; defaults reproduce the reference's behaviour):
       variant        "auto" | "gather" | "lds" | "wave"  -- kernel selection (GMPI_VARIANT_*)
       strict_order   one rounding per reference op also in the blend (bit-identical to the oracle)
-      range_check    "touched" (default: alpha/rgba range asserted on the texels the render samples, free),
-                     "full" (extra exhaustive pass = the reference's min/max over the whole volume), "off"
+      range_check    "touched" (alpha/rgba range asserted on the texels the render samples, free), "full" (extra
+                     exhaustive pass = the reference's min/max over the whole volume, mpi.py:185-187 /
+                     mpi_renderer.py:447-449), "off"; None = `MPI.DEFAULT_RANGE_CHECK` ("touched"; `install()` sets
+                     it to "full" so that a swapped-in module asserts exactly what the reference asserts).
+                     Both modes test all four channels: the reference's `MPI.check_shapes` tests alpha only, but
+                     its only caller (`MPIRenderer.render`) has asserted the whole rgba tensor just before.
       on_out_of_plane "exit" (reference: diagnostics + sys.exit(1), mpi.py:110-128) | "raise" (RuntimeError)
     """
 
+    DEFAULT_RANGE_CHECK = "touched"
+
     def __init__(self, align_corners=True, variant: str = "auto", strict_order: bool = False,
-                 range_check: str = "touched", on_out_of_plane: str = "exit"):
+                 range_check: Optional[str] = None, on_out_of_plane: str = "exit"):
         super().__init__()
         self._align_corners = align_corners
+        if range_check is None:
+            range_check = MPI.DEFAULT_RANGE_CHECK
         assert variant in _lib.VARIANTS, variant
         assert range_check in ("touched", "full", "off"), range_check
         assert on_out_of_plane in ("exit", "raise"), on_out_of_plane
@@ -118,10 +127,13 @@ class MPI(nn.Module):
                           status=status, defer_status=defer_status, out=out)
             color, depth, T, st = _RenderFunction.apply(rgba, self, dhw, ray_dir, eye_pos, z_dir, kwargs)
             return dict(color=color, depth=depth, T=T if want_transmittance else None, status=st)
-        if not rgba.is_cuda:
+        lib = _lib.load_library()
+        # (`records_only`: a stub library that records the parameter structs instead of launching -- the seam test of
+        #  tests/test_install_reference.py drives the reference's own MPIRenderer.render into this module with it)
+        on_device = rgba.is_cuda
+        if not on_device and not getattr(lib, "records_only", False):
             raise _lib.GmpiError("MPI.forward needs tensors on a ROCm device: this package has no CPU path "
                                  f"(got rgba on {rgba.device})")
-        lib = _lib.load_library()
         dev = rgba.device
         if rgba.dtype not in _DTYPES:
             rgba = rgba.float()
@@ -194,8 +206,8 @@ class MPI(nn.Module):
         p.rgb_out, p.depth_out = color.data_ptr(), depth.data_ptr()
         p.transmittance_out = T.data_ptr() if T is not None else None
         p.status = status.data_ptr()
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream if on_device else 0
+        with (torch.cuda.device(dev) if on_device else contextlib.nullcontext()):
             if self.range_check == "full":
                 vol = rgba if rgba.is_contiguous() else rgba.contiguous()
                 _lib.check(lib.gmpi_rgba_range_check_launch(vol.data_ptr(), p.rgba_dtype, vol.numel(),
@@ -214,6 +226,8 @@ class MPI(nn.Module):
         word = int(status[0].item())  # the only host sync of a render call
         if word == 0:
             return
+        if word & _lib.STATUS_BAD_VIEW_INDEX:
+            raise IndexError("view_to_mpi holds an index outside [0, #mpi)")
         if word & _lib.STATUS_RGBA_RANGE:
             raise AssertionError("Expected alpha to be within the the range [0, 1]")  # mpi.py:185-187
         if word & _lib.STATUS_CAMERA_BEHIND_PLANE:
@@ -256,27 +270,51 @@ class MPI(nn.Module):
 
 
 class _RenderFunction(torch.autograd.Function):
-    """autograd bridge: forward = gmpi_mpi_render_launch, backward = gmpi_mpi_render_backward_launch (d/d rgba)."""
+    """autograd bridge: forward = gmpi_mpi_render_launch, backward = gmpi_mpi_render_backward_launch (d/d rgba).
+
+    Everything the backward reads is kept through `save_for_backward` (so an in-place update of the volume between
+    forward and backward raises instead of producing gradients of overwritten memory), the parameter struct is rebuilt
+    from the saved tensors, and the transmittance the backward sweep starts from lives in a buffer private to this
+    node (never a caller-supplied `out["T"]`, which a batch driver reuses across launches)."""
 
     @staticmethod
     def forward(ctx, rgba, mpi, dhw, ray_dir, eye_pos, z_dir, kwargs):
-        # the backward starts from the final transmittance, so the forward always writes it
-        res = mpi.render_views(rgba.detach(), dhw, ray_dir, eye_pos, z_dir, _in_autograd_fn=True,
-                               **dict(kwargs, want_transmittance=True))
-        ctx.params, ctx.keep = res.pop("_bwd")
-        ctx.rgba_dtype, ctx.rgba_shape = rgba.dtype, tuple(rgba.shape)
+        kw = dict(kwargs, want_transmittance=True)
+        user_out = kw.get("out") or {}
+        kw["out"] = {k: v for k, v in user_out.items() if k != "T"}   # private T
+        res = mpi.render_views(rgba.detach(), dhw, ray_dir, eye_pos, z_dir, _in_autograd_fn=True, **kw)
+        p, keep = res.pop("_bwd")
         T = res["T"]
-        ctx.t_final = T  # (kept alive: ctx.params holds its raw pointer)
+        if kwargs.get("want_transmittance") and user_out.get("T") is not None:
+            user_out["T"].copy_(T)
+        vol, dhw_d, ray_d, eye_d, zd_d, v2m = keep
+        ctx.has_v2m = v2m is not None
+        ctx.save_for_backward(vol, dhw_d, ray_d, eye_d, zd_d, T, *([v2m] if v2m is not None else []))
+        ctx.scalars = dict(flags=p.flags, variant=p.variant, rgba_dtype=p.rgba_dtype, N=p.N, M=p.M, D=p.D, Ht=p.Ht, Wt=p.Wt,
+                           H=p.H, W=p.W, views_per_mpi=p.views_per_mpi)
+        ctx.in_dtype, ctx.in_shape = rgba.dtype, tuple(rgba.shape)
         ctx.mark_non_differentiable(res["status"], T)  # gradient w.r.t. the transmittance output is not provided
         return res["color"], res["depth"], T, res["status"]
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_T, g_status):
         lib = _lib.load_library()
-        p = ctx.params
-        rgba = ctx.keep[0]
-        dev = rgba.device
-        grad = torch.zeros(ctx.rgba_shape, dtype=torch.float32, device=dev)
+        saved = ctx.saved_tensors
+        vol, dhw, ray_dir, eye_pos, z_dir, T = saved[:6]
+        v2m = saved[6] if ctx.has_v2m else None
+        dev = vol.device
+        p = _lib.GmpiRenderParams()
+        p.struct_size = ctypes.sizeof(_lib.GmpiRenderParams)
+        for k, v in ctx.scalars.items():
+            setattr(p, k, v)
+        p.rgba = vol.data_ptr()
+        for i, s in enumerate(vol.stride()):
+            p.rgba_stride[i] = s
+        p.view_to_mpi = v2m.data_ptr() if v2m is not None else None
+        p.dhw, p.ray_dir, p.eye_pos, p.z_dir = dhw.data_ptr(), ray_dir.data_ptr(), eye_pos.data_ptr(), z_dir.data_ptr()
+        p.rgb_out = p.depth_out = p.status = None
+        p.transmittance_out = T.data_ptr()
+        grad = torch.zeros(ctx.in_shape, dtype=torch.float32, device=dev)
         if g_color is None:
             g_color = torch.zeros((p.N, 3, p.H, p.W), dtype=torch.float32, device=dev)
         g_color = g_color.to(torch.float32).contiguous()
@@ -286,7 +324,7 @@ class _RenderFunction(torch.autograd.Function):
             _lib.check(lib.gmpi_mpi_render_backward_launch(
                 ctypes.byref(p), g_color.data_ptr(), g_depth.data_ptr() if g_depth is not None else None,
                 grad.data_ptr(), gstride, torch.cuda.current_stream(dev).cuda_stream), "gmpi_mpi_render_backward_launch")
-        return grad.to(ctx.rgba_dtype), None, None, None, None, None, None
+        return grad.to(ctx.in_dtype), None, None, None, None, None, None
 
 
 HipMPI = MPI

@@ -58,7 +58,7 @@ class MPIRenderer:
                  use_xyz_ztype="depth", use_normalized_xyz=False, normalized_xyz_range="-11",
                  use_confined_volume=False, device=torch.device("cpu"),
                  # extensions (keyword-only, defaults = reference behaviour)
-                 kernel_variant="auto", strict_order=False, range_check="touched", on_out_of_plane="exit",
+                 kernel_variant="auto", strict_order=False, range_check=None, on_out_of_plane="exit",
                  ray_backend="auto"):
         self.mpi = MPI(align_corners=mpi_align_corners, variant=kernel_variant, strict_order=strict_order,
                        range_check=range_check, on_out_of_plane=on_out_of_plane)

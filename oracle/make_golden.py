@@ -8,6 +8,8 @@ pin for the oracle (oracle/mpi_oracle.c), for the host-side geometry mirror and 
   render_*.npz   inputs (rgba by seed via oracle.synth_rgba, camera tensors exactly as the
                  reference's `sample_cam_poses` produced them) + outputs of the reference
                  `MPIRenderer.render` / `MPI.forward` (gmpi/core/mpi_renderer.py:387, mpi.py:308)
+  backward_*.npz gradient of the reference w.r.t. the RGBA volume (autograd through MPIRenderer.render / MPI.forward,
+                 the G-step's backward, train.py:740-779) for seeded output gradients
   geometry.npz   plane depths / dhws / c2w / rays / sampled poses of the reference's host-side
                  helpers (mpi_utils.py:21,787,652; cam_utils.py:734; camera.py:182;
                  mpi_renderer.py:337) for the dataset presets
@@ -277,7 +279,69 @@ def run_light_render():
     print("wrote light_render", {k: v.shape for k, v in out.items()})
 
 
+def run_backward_cases(ns):
+    """Gradient of the reference w.r.t. the RGBA volume: autograd through the reference's own MPIRenderer.render /
+    MPI.forward (mpi.py:308-436), exactly what the G-step back-propagates (train.py:740-779), fp32 on the CPU.
+    loss = sum(rgb * g_rgb) + sum(depth * g_depth) with seeded normal g's."""
+    keys = ["batch_yaws", "batch_pitches", "batch_tf_c2w", "batch_ray_dir", "batch_eye_pos", "batch_z_dir"]
+    cases = [
+        dict(name="ffhq_d8_32", D=8, S=32, B=2, seed=31, ac=True),
+        dict(name="ffhq_d8_32_opaque", D=8, S=32, B=1, seed=32, ac=True, opaque=True),
+        dict(name="ffhq_d6_tex40_img24_ac0", D=6, S=24, tex=40, B=2, seed=33, ac=False),
+    ]
+    for case in cases:
+        with quiet():
+            r = ref_import.make_reference_renderer(ns, "FFHQ", case["D"], align_corners=case["ac"])
+            r.set_cam(r.cam_fov, case["S"], case["S"])
+        B, D, S, T = case["B"], case["D"], case["S"], case.get("tex", case["S"])
+        torch.manual_seed(case["seed"])
+        cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+        rgba = oracle.synth_rgba(case["seed"], (B, D, 4, T, T), last_alpha_one=True)
+        if case.get("opaque"):  # exactly and nearly opaque planes in the middle of the stack (the 1e-10 term matters)
+            rgba[:, 2, 3, :, : T // 2] = 1.0
+            rgba[:, 4, 3, :, T // 4:] = np.float32(1.0 - 1e-6)
+            rgba[:, 3:6, 3, : T // 3, :] = 1.0
+        vol = torch.from_numpy(rgba).requires_grad_(True)
+        with quiet():
+            rgb, depth, _, _ = r.render(vol, S, S, given_cam_infos=dict(zip(keys, cam)))
+        g = torch.Generator().manual_seed(case["seed"] + 100)
+        g_rgb, g_depth = torch.randn(rgb.shape, generator=g), torch.randn(depth.shape, generator=g)
+        ((rgb * g_rgb).sum() + (depth * g_depth).sum()).backward()
+        dhw = r.dynamic_mpi_plane_dhws.reshape(1, -1, 3).expand(B, -1, -1)
+        np.savez(os.path.join(OUT, f"backward_{case['name']}.npz"), meta=json.dumps(case), rgba=rgba,
+                 dhw=dhw.contiguous().numpy().astype(np.float32), ray_dir=torch.cat(cam[3]).numpy(),
+                 eye=torch.cat(cam[4]).numpy(), zdir=torch.cat(cam[5]).numpy(), g_rgb=g_rgb.numpy(), g_depth=g_depth.numpy(),
+                 ref_rgb_pm1=rgb.detach().numpy(), ref_depth=depth.detach().numpy(), ref_grad_rgba=vol.grad.numpy())
+        print("wrote backward", case["name"], "max |grad|", float(vol.grad.abs().max()))
+    # MPI.forward called directly with a ragged views-per-MPI list (M = 2 MPIs, (2, 1) views): gradients of two views
+    # accumulate into MPI 0
+    with quiet():
+        r = ref_import.make_reference_renderer(ns, "FFHQ", 5)
+        r.set_cam(r.cam_fov, 20, 20)
+    torch.manual_seed(34)
+    cam = r.sample_cam_poses(3, 0.0, 0.289, 0.0, 0.127, True)
+    rgba = oracle.synth_rgba(34, (2, 5, 4, 24, 28))
+    vol = torch.from_numpy(rgba).requires_grad_(True)
+    dhw = r.dynamic_mpi_plane_dhws.reshape(1, -1, 3).expand(2, -1, -1).contiguous()
+    color, depth = r.mpi(batch_rgba=vol, batch_dhw=dhw, batch_ray_dir=[torch.cat(cam[3][:2]), cam[3][2]],
+                         batch_eye_pos=[torch.cat(cam[4][:2]), cam[4][2]], batch_z_dir=[torch.cat(cam[5][:2]), cam[5][2]],
+                         separate_background=None)
+    g = torch.Generator().manual_seed(134)
+    g_rgb, g_depth = torch.randn(color.shape, generator=g), torch.randn(depth.shape, generator=g)
+    ((color * g_rgb).sum() + (depth * g_depth).sum()).backward()
+    np.savez(os.path.join(OUT, "backward_forward_ragged_views.npz"),
+             meta=json.dumps(dict(seed=34, M=2, D=5, tex=(24, 28), S=20, views_per_mpi=[2, 1], ac=True)), rgba=rgba,
+             dhw=dhw.numpy(), ray_dir=torch.cat(cam[3]).numpy(), eye=torch.cat(cam[4]).numpy(), zdir=torch.cat(cam[5]).numpy(),
+             view_to_mpi=np.array([0, 0, 1], np.int32), g_rgb=g_rgb.numpy(), g_depth=g_depth.numpy(),
+             ref_color01=color.detach().numpy(), ref_depth=depth.detach().numpy(), ref_grad_rgba=vol.grad.numpy())
+    print("wrote backward_forward_ragged_views")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "backward":
+        torch.set_num_threads(1)
+        run_backward_cases(ref_import.import_reference())
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "light":
         os.makedirs(OUT, exist_ok=True)
         torch.set_num_threads(1)
@@ -290,6 +354,7 @@ def main():
     for case in RENDER_CASES:
         run_render_case(ns, case)
     run_multiview_case(ns)
+    run_backward_cases(ns)
     run_geometry(ns)
     run_light_depth()
     run_light_render()

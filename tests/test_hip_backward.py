@@ -1,6 +1,7 @@
 """Backward of the fused render (gradient w.r.t. the RGBA volume; reference: autograd through MPI.forward in the
-G-step, gmpi/train.py:740-779).  The HIP backward (fp32, atomics) is compared with torch autograd on a float64
-restatement of the same forward (tests/_torch_ref.py)."""
+G-step, gmpi/train.py:740-779).  The HIP backward (fp32, atomics) is compared with (1) fixtures made by the reference's own
+autograd (tests/golden/backward_*.npz, oracle/make_golden.py) and (2) torch autograd on a float64 restatement of the same
+forward (tests/_torch_ref.py) for the shapes the fixtures do not cover."""
 import numpy as np
 import pytest
 import torch
@@ -129,3 +130,72 @@ def test_no_gradient_to_geometry_and_no_grad_mode():
     with torch.no_grad():
         out = mpi.render_views(t(rgba).requires_grad_(True), t(dhw), t(ray), t(eye), t(zd))
     assert not out["color"].requires_grad
+
+
+def _backward_fixtures():
+    import glob
+    import os
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "backward_*.npz")))
+
+
+@pytest.mark.parametrize("name", _backward_fixtures())
+def test_backward_matches_reference_autograd_fixtures(name):
+    """d loss / d rgba of the HIP backward against fixtures made by the REFERENCE'S OWN autograd (oracle/make_golden.py
+    `run_backward_cases`: MPIRenderer.render / MPI.forward under grad on the CPU, fp32 -- what the G-step
+    back-propagates, train.py:740-779), incl. exactly / nearly opaque planes in the middle of the stack, a texture
+    finer than the image with align_corners=False, and a ragged views-per-MPI list whose views accumulate into one MPI."""
+    from _util import load_npz
+    from ml_gmpi_amd import MPI
+    fx = load_npz(name + ".npz")
+    meta = fx["meta"]
+    pm1 = "ref_rgb_pm1" in fx
+    ref_c = fx["ref_rgb_pm1"] if pm1 else fx["ref_color01"]
+    ref_g = fx["ref_grad_rgba"]
+    N = fx["ray_dir"].shape[0]
+    v2m = fx["view_to_mpi"] if "view_to_mpi" in fx else np.arange(N, dtype=np.int32)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    scale = np.abs(ref_g).max()
+    for variant in ("auto", "gather"):
+        vol = t(fx["rgba"]).requires_grad_(True)
+        mpi = MPI(align_corners=meta["ac"], variant=variant, on_out_of_plane="raise")
+        out = mpi.render_views(vol, t(fx["dhw"]), t(fx["ray_dir"]), t(fx["eye"]), t(fx["zdir"]), view_to_mpi=t(v2m.astype(np.int32)),
+                               check_last_plane=False, out_pm1=pm1)
+        assert np.abs(out["color"].detach().cpu().numpy() - ref_c).max() <= 1e-5
+        assert np.abs(out["depth"].detach().cpu().numpy() - fx["ref_depth"]).max() <= 1e-5
+        ((out["color"] * t(fx["g_rgb"])).sum() + (out["depth"] * t(fx["g_depth"])).sum()).backward()
+        got = vol.grad.cpu().numpy()
+        assert np.isfinite(got).all()
+        # fp32 autograd on the CPU vs fp32 atomics on the GPU: both carry ~1e-6 relative noise per term
+        assert np.abs(got - ref_g).max() <= 3e-5 * scale, (variant, np.abs(got - ref_g).max(), scale)
+        big = np.abs(ref_g) > 1e-3 * scale
+        assert np.max(np.abs(got[big] - ref_g[big]) / np.abs(ref_g[big])) <= 5e-3, variant
+
+
+def test_inplace_update_between_forward_and_backward_is_detected():
+    """The volume, the camera tensors and the transmittance the backward starts from are kept through save_for_backward:
+    overwriting the volume before backward() must raise (torch's version counter), not differentiate overwritten memory;
+    and a caller-supplied out["T"] buffer that is reused by the next launch must not disturb an earlier graph."""
+    from ml_gmpi_amd import MPI
+    rgba, dhw, ray, eye, zd, v2m = _setup(2, 2, 6, 32, 32, 32, 32, seed=51)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mpi = MPI(align_corners=True, on_out_of_plane="raise")
+    base = t(rgba)
+    leaf = base.clone().requires_grad_(True)
+    vol = leaf * 1.0
+    out = mpi.render_views(vol, t(dhw), t(ray), t(eye), t(zd), check_last_plane=False)
+    vol.mul_(0.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out["color"].sum().backward()
+    # shared output buffers (the batch driver's pattern): two graphs, one T buffer
+    shared = dict(T=torch.empty((2, 1, 32, 32), device=dev))
+    a = base.clone().requires_grad_(True)
+    b = (base * 0.5).clone().requires_grad_(True)
+    out_a = mpi.render_views(a, t(dhw), t(ray), t(eye), t(zd), check_last_plane=False, want_transmittance=True, out=shared)
+    out_b = mpi.render_views(b, t(dhw), t(ray), t(eye), t(zd), check_last_plane=False, want_transmittance=True, out=shared)
+    out_a["color"].sum().backward()
+    alone = base.clone().requires_grad_(True)
+    mpi.render_views(alone, t(dhw), t(ray), t(eye), t(zd), check_last_plane=False)["color"].sum().backward()
+    assert torch.allclose(a.grad, alone.grad, rtol=1e-4, atol=1e-6)
+    assert torch.equal(shared["T"], out_b["T"])

@@ -231,6 +231,29 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == -2  # zero extents
     p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W, p.views_per_mpi = 1, 1, 1, 4, 4, 4, 4, 1
     assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == -1  # null pointers
+    # undefined flag bits never reach a kernel (round-1's ablation bits 16-21 rendered zeros with rc 0)
+    dev = torch.device("cuda:0")
+    buf = torch.zeros(4096, dtype=torch.float32, device=dev)
+    for name in ("rgba", "dhw", "ray_dir", "eye_pos", "z_dir", "rgb_out", "depth_out"):
+        setattr(p, name, buf.data_ptr())
+    p.rgba_stride[:] = [64, 64, 16, 4, 1]
+    for bit in (5, 16, 17, 18, 19, 24, 31):
+        p.flags = L.FLAG_ALIGN_CORNERS | (1 << bit)
+        assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == -7, bit  # GMPI_E_FLAGS
+    p.flags = L.FLAG_ALIGN_CORNERS
+    # more views than the gather kernel's grid.z (and the backward's grid) can carry: refused, not an opaque launch error
+    p.N, p.M, p.views_per_mpi, p.variant = 70000, 1, 70000, L.VARIANT_GATHER
+    assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == -2
+    assert lib.gmpi_mpi_render_backward_launch(ctypes.byref(p), buf.data_ptr(), None, buf.data_ptr(), (ctypes.c_int64 * 5)(64, 64, 16, 4, 1), None) == -2
+
+
+def test_view_to_mpi_out_of_range_is_reported_not_dereferenced():
+    rgba, dhw, ray, eye, zd = _random_case(seed=12, B=2, D=4, S=64)
+    for variant in variants():
+        for bad in ([0, 2], [-1, 1], [0, 1 << 20]):
+            with pytest.raises(IndexError):
+                hip_render(rgba, dhw, ray, eye, zd, variant=variant, view_to_mpi=bad)
+        hip_render(rgba, dhw, ray, eye, zd, variant=variant, view_to_mpi=[1, 0])
 
 
 def test_mpi_forward_signature_and_renderer_render():
@@ -316,3 +339,36 @@ def test_device_rays_are_bit_identical_to_the_reference_cpu_rays(name):
     assert np.array_equal(ray.cpu().numpy(), fx["ray_dir"])
     assert np.array_equal(eye.cpu().numpy(), fx["eye"])
     assert np.array_equal(zd.cpu().numpy(), fx["zdir"])
+
+
+def test_division_through_reciprocal_is_exact():
+    """gmpi_device.hpp div_by_recip (default mode: mpi.py:76, 89-90 through hoisted reciprocals) against the IEEE
+    division on 2^32 operand pairs: the renderer's operand ranges, full-range significands, and the one divisor
+    pattern the correction step's proof treats separately.  Not one quotient may differ."""
+    L = _lib()
+    lib = L.load_library()
+    dev = torch.device("cuda:0")
+    mism = torch.zeros(4, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for seed in (1, 2):
+        L.check(lib.gmpi_selftest_division_launch(1 << 31, seed, mism.data_ptr(), st), "gmpi_selftest_division_launch")
+    torch.cuda.synchronize()
+    assert mism.cpu().tolist() == [0, 0, 0, 0], mism.cpu().tolist()
+    assert lib.gmpi_selftest_division_launch(16, 0, None, st) == -1  # GMPI_E_NULL
+
+
+@pytest.mark.parametrize("extreme", [False, True])
+def test_default_mode_samples_the_strict_texels(extreme):
+    """One opaque white-noise plane at a time: the default mode (reciprocal divisions, FMA blend) may differ from the
+    strict-order mode only by the rounding of the bilinear sum (<= 2e-7); a sample position that slipped by one ulp
+    (6e-5 texel at 1024^2) would move the result by up to 6e-5 * |texel difference|."""
+    rgba, dhw, ray, eye, zd = _random_case(seed=11, B=2, D=96, S=1024, extreme=extreme)
+    for k in (0, 47, 94, 95):
+        vol = rgba[:, k:k + 1].clone()
+        vol[:, :, 3] = 1.0
+        geo = dhw[:, k:k + 1].contiguous()
+        for variant in variants():
+            strict = hip_render(vol, geo, ray, eye, zd, variant=variant, strict=True, check_last=False)
+            fast = hip_render(vol, geo, ray, eye, zd, variant=variant, check_last=False)
+            assert np.abs(fast["color"] - strict["color"]).max() <= 1e-6, (k, variant, np.abs(fast["color"] - strict["color"]).max())
+            assert np.abs(fast["depth"] - strict["depth"]).max() <= 1e-6, (k, variant)

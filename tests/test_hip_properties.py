@@ -122,3 +122,42 @@ def test_full_size_window_against_oracle(shape):
             for key in ("color", "depth", "T"):
                 got = out[key][:, :, y0:y0 + 64, x0:x0 + 64].cpu().numpy()
                 assert np.array_equal(got, orc[key]), (variant, key, y0, x0, np.abs(got - orc[key]).max())
+
+
+def test_full_size_windows_config2_and_config4_against_oracle():
+    """BASELINE config 2 (256^2 x 96, 8 views, fp32) and config 4 (512^2 x 96, 8 camera-path views of ONE MPI, yaw sweep
+    0.5 ... -0.5 as render_video.py:236-237: the views_per_mpi > 1 tile interleave) at full size: strict mode, windows
+    against the oracle, every view."""
+    # ---- config 2 ----
+    r, rgba, dhw, ray, eye, zd = setup(S=256, D=96, B=8, dtype=torch.float32, seed=8)
+    vol = rgba.cpu().numpy()
+    for variant in variants():
+        out = run(r, rgba, dhw, ray, eye, zd, variant, strict=True)
+        for (y0, x0) in [(0, 0), (192, 192), (101, 37)]:
+            win = ray[:, :, y0:y0 + 64, x0:x0 + 64].contiguous().cpu()
+            orc = oracle.render(vol, dhw.cpu(), win, eye.cpu(), zd.cpu(), threads=True)
+            for key in ("color", "depth", "T"):
+                got = out[key][:, :, y0:y0 + 64, x0:x0 + 64].cpu().numpy()
+                assert np.array_equal(got, orc[key]), ("cfg2", variant, key, y0, x0, np.abs(got - orc[key]).max())
+    # ---- config 4: one MPI, 8 views ----
+    from ml_gmpi_amd import make_renderer
+    dev = torch.device(DEV)
+    S, D, B = 512, 96, 8
+    r = make_renderer("FFHQ", n_planes=D, device=dev, on_out_of_plane="raise")
+    r.set_cam(r.cam_fov, S, S)
+    g = torch.Generator(device=dev).manual_seed(9)
+    rgba = torch.rand((1, D, 4, S, S), device=dev, generator=g)
+    yaw = torch.linspace(0.5, -0.5, B).view(-1, 1)
+    cam = r.sample_cam_poses(B, 0, 0, 0, 0, False, given_yaws=yaw, given_pitches=torch.zeros(B, 1))
+    ray, eye, zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+    dhw = r._dhw_on_device().expand(1, -1, -1).contiguous()
+    vol = rgba.cpu().numpy()
+    v2m = np.zeros(B, dtype=np.int32)
+    for variant in variants():
+        out = run(r, rgba, dhw, ray, eye, zd, variant, strict=True, views_per_mpi=B)
+        for (y0, x0) in [(0, 0), (S - 64, S - 64), (S // 2 - 32, 200)]:
+            win = ray[:, :, y0:y0 + 64, x0:x0 + 64].contiguous().cpu()
+            orc = oracle.render(vol, dhw.cpu(), win, eye.cpu(), zd.cpu(), view_to_mpi=v2m, threads=True)
+            for key in ("color", "depth", "T"):
+                got = out[key][:, :, y0:y0 + 64, x0:x0 + 64].cpu().numpy()
+                assert np.array_equal(got, orc[key]), ("cfg4", variant, key, y0, x0, np.abs(got - orc[key]).max())

@@ -46,3 +46,80 @@ def test_reference_renderer_with_patched_mpi_keeps_its_geometry():
         assert torch.equal(r.static_mpi_plane_dhws, ours.static_mpi_plane_dhws)
     finally:
         ml_gmpi_amd.uninstall()
+
+
+class _RecordingLibrary:
+    """Stands in for libgmpi_render.so: every launch records a copy of its arguments and returns GMPI_OK."""
+    records_only = True
+
+    def __init__(self):
+        self.calls = []
+
+    def _copy_params(self, pref):
+        import ctypes
+        from ml_gmpi_amd import _lib
+        src = ctypes.cast(pref, ctypes.POINTER(_lib.GmpiRenderParams)).contents
+        dst = _lib.GmpiRenderParams()
+        ctypes.memmove(ctypes.byref(dst), ctypes.byref(src), ctypes.sizeof(dst))
+        return dst
+
+    def gmpi_mpi_render_launch(self, pref, stream):
+        self.calls.append(("render", self._copy_params(pref), stream))
+        return 0
+
+    def gmpi_rgba_range_check_launch(self, ptr, dtype, count, status, stream):
+        self.calls.append(("range_check", (ptr, dtype, count, status), stream))
+        return 0
+
+
+def test_reference_render_drives_the_hip_mpi_through_its_seam(monkeypatch):
+    """The reference's OWN `MPIRenderer.render` (mpi_renderer.py:387-469) with only `MPI` swapped: the call at
+    mpi_renderer.py:451-461 (keyword arguments, per-view lists, c2w_mat, sphere_c) must reach `MPI.forward` and be marshalled
+    into the GmpiRenderParams the C ABI expects.  The library is replaced by a recorder (no GPU in this container)."""
+    import ref_import
+    ns = ref_import.import_reference()
+    import ml_gmpi_amd
+    from ml_gmpi_amd import _lib
+    rec = _RecordingLibrary()
+    monkeypatch.setattr(_lib, "load_library", lambda: rec)
+    seen = {}
+    orig_forward = ml_gmpi_amd.MPI.forward
+
+    def spy(self, **kw):
+        seen.update(kw)
+        return orig_forward(self, **kw)
+
+    monkeypatch.setattr(ml_gmpi_amd.MPI, "forward", spy)
+    B, D, S, T = 3, 6, 20, 24
+    try:
+        ml_gmpi_amd.install(patch_renderer=False)        # default: the reference's whole-volume range assertion
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = ref_import.make_reference_renderer(ns, "FFHQ", D)
+            r.set_cam(r.cam_fov, S, S)
+        assert isinstance(r.mpi, ml_gmpi_amd.MPI) and r.mpi.range_check == "full"
+        torch.manual_seed(5)
+        rgba = torch.rand(B, D, 4, T, T)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rgb, depth, c2w, angles = r.render(rgba, S, S, assert_not_out_of_last_plane=True)
+    finally:
+        ml_gmpi_amd.uninstall()
+    assert ml_gmpi_amd.MPI.DEFAULT_RANGE_CHECK == "touched"
+    # what the reference passed through the seam (mpi_renderer.py:451-461)
+    assert set(seen) == {"batch_rgba", "batch_dhw", "batch_ray_dir", "batch_eye_pos", "batch_z_dir", "separate_background",
+                         "assert_not_out_of_last_plane", "c2w_mat", "sphere_c"}
+    assert seen["separate_background"] is None and seen["assert_not_out_of_last_plane"] is True
+    assert len(seen["batch_ray_dir"]) == B and tuple(seen["batch_ray_dir"][0].shape) == (1, 3, S, S)
+    assert tuple(seen["c2w_mat"].shape) == (B, 4, 4) and len(seen["sphere_c"]) == 3
+    # what reached the C ABI: the exhaustive range check first, then ONE render launch
+    assert [c[0] for c in rec.calls] == ["range_check", "render"]
+    ptr, dtype, count, status_ptr = rec.calls[0][1]
+    assert dtype == _lib.DTYPE_F32 and count == B * D * 4 * T * T
+    p = rec.calls[1][1]
+    assert (p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W, p.views_per_mpi) == (B, B, D, T, T, S, S, 1)
+    assert p.view_to_mpi is None and p.rgba == ptr and p.status == status_ptr
+    assert list(p.rgba_stride) == [D * 4 * T * T, 4 * T * T, T * T, T, 1]
+    assert p.rgba_dtype == _lib.DTYPE_F32 and p.variant == _lib.VARIANT_AUTO
+    # MPI.forward returns colour in [0,1]: the reference applies 2c-1 itself (mpi_renderer.py:467), so OUT_PM1 is off
+    assert p.flags == (_lib.FLAG_ALIGN_CORNERS | _lib.FLAG_CHECK_LAST_PLANE | _lib.FLAG_CHECK_RANGE)
+    assert p.transmittance_out is None and p.rgb_out and p.depth_out
+    assert tuple(rgb.shape) == (B, 3, S, S) and tuple(depth.shape) == (B, 1, S, S) and tuple(angles.shape) == (B, 2)

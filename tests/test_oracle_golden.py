@@ -71,3 +71,18 @@ def test_oracle_transmittance_consistency():
     rgba[:, :, :3] = 0.25  # constant colour: C = 0.25 * sum(w)
     out = oracle.render(rgba, fx["dhw"], fx["ray_dir"], fx["eye"], fx["zdir"])
     assert np.abs(out["color"] - 0.25 * (1.0 - out["T"])).max() <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["backward_ffhq_d8_32", "backward_ffhq_d8_32_opaque", "backward_ffhq_d6_tex40_img24_ac0",
+                                  "backward_forward_ragged_views"])
+def test_oracle_matches_the_forward_of_the_backward_fixtures(name):
+    """The gradient fixtures (reference autograd, train.py:740-779) also carry the reference's forward values: exactly and
+    nearly opaque planes in the middle of the stack, a texture finer than the image with align_corners=False."""
+    fx = load_npz(name + ".npz")
+    v2m = fx.get("view_to_mpi")
+    out = oracle.render(fx["rgba"], fx["dhw"], fx["ray_dir"], fx["eye"], fx["zdir"], view_to_mpi=v2m, align_corners=fx["meta"]["ac"])
+    if "ref_rgb_pm1" in fx:
+        assert np.abs(2.0 * out["color"] - 1.0 - fx["ref_rgb_pm1"]).max() <= 2 * TOL
+    else:
+        assert np.abs(out["color"] - fx["ref_color01"]).max() <= TOL
+    assert np.abs(out["depth"] - fx["ref_depth"]).max() <= TOL
