@@ -96,9 +96,31 @@ def cpu_baseline(preset, S, D, dtype, budget_s=20.0):
         reps += 1
         if time.perf_counter() - t0 > budget_s or reps >= 20:
             break
-    return dict(value=round(S * S * D / best / 1e6, 2), unit="Mpix*planes/s", cores=oracle.num_threads(True),
-                kind="port", sample=f"1 view {S}x{S}x{D} ({dtype} values), best of {reps} runs of oracle/mpi_oracle.c (OpenMP)",
-                views_per_s=round(1.0 / best, 4))
+    res = dict(value=round(S * S * D / best / 1e6, 2), unit="Mpix*planes/s", cores=oracle.num_threads(True),
+               kind="port", sample=f"1 view {S}x{S}x{D} ({dtype} values), best of {reps} runs of oracle/mpi_oracle.c (OpenMP)",
+               views_per_s=round(1.0 / best, 4))
+    # second leg: the reference's own op chain (MPIRenderer.render -> MPI.forward -> homography as the same PyTorch calls,
+    # oracle/torch_ops.py; the reference itself is not on the GPU box), all host cores, one view, warm-up + best of <= 3
+    try:
+        import torch_ops
+        nthreads = os.cpu_count() or 1
+        torch.set_num_threads(nthreads)
+        t_args = (rgba, r.static_mpi_plane_dhws, cam[3][0], cam[4][0], cam[5][0])
+        with torch.no_grad():
+            torch_ops.renderer_render(*t_args)
+            best_ops, t0 = float("inf"), time.perf_counter()
+            for _ in range(3):
+                t1 = time.perf_counter()
+                torch_ops.renderer_render(*t_args)
+                best_ops = min(best_ops, time.perf_counter() - t1)
+                if time.perf_counter() - t0 > budget_s / 2:
+                    break
+        res["reference_ops"] = dict(value=round(S * S * D / best_ops / 1e6, 2), unit="Mpix*planes/s", cores=nthreads, kind="reference-ops",
+                                    sample=f"1 view {S}x{S}x{D}: the reference's op chain (mpi_renderer.py:444-467, mpi.py:60-153, 321-436) "
+                                           "as the same PyTorch CPU calls, oracle/torch_ops.py", views_per_s=round(1.0 / best_ops, 4))
+    except Exception as e:  # memory (10 GB per 1024^2 x 96 view) or a missing module must not cost the bench line
+        res["reference_ops"] = dict(error=str(e)[:200])
+    return res
 
 
 def main():
@@ -136,7 +158,8 @@ def main():
     r.set_cam(r.cam_fov, S, S)
     # ---- synthetic inputs, resident in HBM --------------------------------------------------------
     n_mpis = 1 if a.workload == "cfg4" else n_views
-    g = torch.Generator(device=dev).manual_seed(1000 * 3 + rank)
+    # config 4 = ONE MPI rendered along a camera path by all ranks: the same volume everywhere; the others: own seeds per rank
+    g = torch.Generator(device=dev).manual_seed(1000 * 3 + (0 if a.workload == "cfg4" else rank))
     rgba = torch.empty((n_mpis, D, 4, S, S), device=dev, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
     for i in range(n_mpis):  # per-MPI fill keeps the transient fp32 copy small
         rgba[i] = torch.rand((D, 4, S, S), device=dev, generator=g).to(rgba.dtype)
@@ -214,13 +237,37 @@ def main():
         abytes = algorithmic_bytes(n_views, D, S, s_in, want_T)
         achieved = abytes / (kern_ms * 1e-3) / 1e9
         fbytes = footprint_bytes(ray, eye, dhw, S, s_in, want_T)
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes per launch, if measured
+        # PMC-derived numbers (tools/prof.sh -> profiles/hbm_traffic.json) are quoted only if they were measured on THESE
+        # kernel sources (hash of csrc/ + the ABI header) and for this workload / variant; otherwise null
+        traffic = valu_floor_ms = None
+        traffic_note = "not measured for these sources"
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.isfile(prof):
             try:
-                traffic = json.load(open(prof)).get(a.workload, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                pj = json.load(open(prof))
+                ent = pj.get("workloads", {}).get(a.workload)
+                if pj.get("source_hash") != _lib.source_hash():
+                    traffic_note = f"profiles/hbm_traffic.json is for sources {pj.get('source_hash')}, these are {_lib.source_hash()}"
+                elif ent and ent.get("variant", "auto") == a.variant and not a.strict:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_note = ent.get("source", "profiles/hbm_traffic.json")
+                    if ent.get("valu_insts_per_launch"):
+                        # wave64 VALU instructions / 1024 SIMDs x the issue cost measured by tools/ubench/clock_probe.hip with
+                        # every CU busy (fp32 1.24 ns, integer 1.73 ns per instruction and SIMD; the kernel's mix ~1.45 ns)
+                        valu_floor_ms = round(ent["valu_insts_per_launch"] / 1024 * 1.45e-6, 4)
+            except Exception as e:
+                traffic_note = f"unreadable: {e}"
+        # streaming-read ceiling of THIS box, measured in-run: one pass of the exhaustive range check over the same volume
+        vol_bytes = rgba.numel() * rgba.element_size()
+        st_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        lib = _lib.load_library()
+        for e0, e1 in st_ev:
+            e0.record()
+            _lib.check(lib.gmpi_rgba_range_check_launch(rgba.data_ptr(), {"f32": 0, "bf16": 1}[dtype], rgba.numel(), status.data_ptr(),
+                                                        torch.cuda.current_stream(dev).cuda_stream), "gmpi_rgba_range_check_launch")
+            e1.record()
+        torch.cuda.synchronize(dev)
+        stream_gbs = vol_bytes / (min(e0.elapsed_time(e1) for e0, e1 in st_ev[1:]) * 1e-3) / 1e9
         line = {
             "metric": "Mpix*planes/s", "value": round(value, 1), "unit": "Mpix*planes/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
@@ -230,7 +277,10 @@ def main():
                        "outputs": "rgb+depth" + ("+transmittance" if want_T else ""), "parallelism": f"views sharded x{world}"},
             "views_per_s": round(n_views * world * a.steps / elapsed, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
+                         # companions: against what a pure streaming read reaches on this box, and the VALU issue floor
+                         "stream_read_gbs": round(stream_gbs, 1), "frac_of_stream_ceiling": round(achieved / stream_gbs, 4),
+                         "valu_floor_ms": valu_floor_ms,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": abytes,
                          # conservative companion: only the texel boxes the views actually touch
                          "footprint_bytes_per_launch": fbytes, "frac_footprint": round(fbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -69,6 +69,20 @@ class GmpiRenderParams(ctypes.Structure):
     ]
 
 
+def source_hash() -> str:
+    """Short hash of the kernel sources (csrc/*.hip, *.hpp, include/gmpi_render.h): profiles/hbm_traffic.json is keyed by it,
+    so that bench.py only quotes PMC-measured traffic that belongs to the kernels it is timing."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hip")) + glob.glob(os.path.join(_PKG, "csrc", "*.hpp")))
+    files.append(os.path.join(os.path.dirname(_PKG), "include", "gmpi_render.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
 def library_path() -> str:
     return _SO
 

@@ -102,3 +102,42 @@ def test_alpha_exact_zero_and_one():
         out = hip_render(rgba, dhw, ray, eye, zd, variant=variant, strict=True, check_last=False)
         assert np.array_equal(out["color"], orc["color"]) and np.array_equal(out["T"], orc["T"])
         assert float(out["T"].max()) <= 1e-6  # opaque last plane: bilinear weights sum to 1 within an ulp
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_guard_band_no_read_outside_the_volume(dtype):
+    """The volume as a strided window of a larger buffer that is NaN everywhere else (2 planes before/after, one channel
+    image before/after, 2 rows above/below, 8 texels left/right of every row): a load that leaves the texture along any
+    axis brings a NaN into the box -- the range check flags it, the output shows it.  Every kernel, tilted cameras whose
+    rays leave the planes (zeros padding on all four borders), bounds done by buffer range checks and predicates only."""
+    from ml_gmpi_amd import MPI
+    dev = torch.device("cuda:0")
+    M, D, Ht, Wt, S = 2, 9, 64, 72, 96
+    g = torch.Generator().manual_seed(77)
+    vol_c = torch.rand((M, D, 4, Ht, Wt), generator=g).to(dtype)
+    big = torch.full((M, D + 4, 6, Ht + 4, Wt + 16), float("nan"), dtype=dtype, device=dev)
+    window = big[:, 2:-2, 1:5, 2:-2, 8:-8]
+    window.copy_(vol_c.to(dev))
+    assert not window.is_contiguous() and window.data_ptr() % 16 == 0
+    ray, eye, zd = _cam(M, S, S, seed=9, tilt=0.9)
+    dhw = _dhw(M, D, ext=0.18, last=0.6)   # small planes: rays of the image border leave planes 0 .. D-2 on every side
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for ac in (True, False):
+        ref = None
+        for variant in variants():
+            for strict in (True, False):
+                mpi = MPI(align_corners=ac, variant=variant, strict_order=strict, range_check="touched", on_out_of_plane="raise")
+                with torch.no_grad():
+                    out = mpi.render_views(window, t(dhw), t(ray), t(eye), t(zd), check_last_plane=False, want_transmittance=True)
+                    alone = mpi.render_views(vol_c.to(dev), t(dhw), t(ray), t(eye), t(zd), check_last_plane=False, want_transmittance=True)
+                torch.cuda.synchronize()
+                for k in ("color", "depth", "T"):
+                    assert torch.isfinite(out[k]).all(), (ac, variant, strict, k)
+                    assert torch.equal(out[k], alone[k]), (ac, variant, strict, k)
+                if strict:
+                    if ref is None:
+                        ref = out
+                    else:
+                        assert all(torch.equal(out[k], ref[k]) for k in ("color", "depth", "T")), (ac, variant)
+        # the zeros padding is really exercised: some pixels see (almost) nothing of the first planes
+        assert float(ref["T"].max()) > 1e-3

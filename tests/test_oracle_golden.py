@@ -86,3 +86,17 @@ def test_oracle_matches_the_forward_of_the_backward_fixtures(name):
     else:
         assert np.abs(out["color"] - fx["ref_color01"]).max() <= TOL
     assert np.abs(out["depth"] - fx["ref_depth"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", render_fixture_names())
+def test_torch_op_chain_matches_reference_render(name):
+    """oracle/torch_ops.py (the reference's op chain as PyTorch calls: bench.py's `reference-ops` CPU baseline) reproduces
+    the reference's own outputs."""
+    import torch
+    import torch_ops
+    fx = load_render_fixture(name)
+    t = torch.from_numpy
+    rgb, depth = torch_ops.renderer_render(t(fx["rgba"]), t(fx["dhw"][0]), t(fx["ray_dir"]), t(fx["eye"]), t(fx["zdir"]),
+                                           align_corners=fx["meta"]["ac"])
+    assert np.abs(rgb.numpy() - fx["ref_rgb_pm1"]).max() <= 2 * TOL
+    assert np.abs(depth.numpy() - fx["ref_depth"]).max() <= TOL

@@ -1,22 +1,33 @@
 #!/bin/bash
-# tools/prof.sh <tag> [bench args...]  -- run on the GPU box (via gpurun).
-# 1) rocprofv3 --kernel-trace --stats (CSV) of bench.py; 2) PMC passes (each in its own run,
-# kernel-trace only, as MI355X_MICROARCH.md prescribes).  Output under gpurun_out/prof_<tag>/.
+# tools/prof.sh <tag>  -- run on the GPU box (via gpurun): rocprofv3 evidence for the bench workloads.
+#   1) kernel trace + stats of the default bench command (cfg3)                      -> $OUT/trace
+#   2) per workload, each in its own rocprofv3 run with --kernel-trace only (MI355X_MICROARCH.md, HBM section):
+#      FETCH_SIZE pass and SQ_INSTS_VALU pass                                          -> $OUT/<workload>/pmc_*
+#   3) issue-slot counters of the headline kernel (cfg3), two passes                   -> $OUT/cfg3/pmc_sq*
+#   4) tools/prof_collect.py: summary.txt + hbm_traffic.json keyed by the kernel-source hash (bench.py quotes it only
+#      for matching sources).  Copy both into profiles/ afterwards.
 set -u
-TAG=$1; shift
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 40 --warmup 10 --no-cpu-baseline $*"
-timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py $ARGS > $OUT/bench_trace.log 2>&1
-tail -1 $OUT/bench_trace.log | cut -c1-400
-pmc() { # name counters...
-  local name=$1; shift
-  timeout 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_$name -o p -- python bench.py $ARGS > $OUT/bench_pmc_$name.log 2>&1
+cd ${GRAFT_REPO_ROOT:-.}
+ARGS="--steps 12 --warmup 4 --no-cpu-baseline"
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+tail -1 $OUT/bench_trace.log | cut -c1-300
+pmc() { # workload name counters...
+  local wl=$1 name=$2; shift 2
+  mkdir -p $OUT/$wl
+  timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$wl/pmc_$name -o p -- python bench.py $ARGS --workload $wl > $OUT/$wl/bench_$name.log 2>&1
+  echo "$wl $name rc=$?"
 }
-pmc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY
-pmc sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAVES
-pmc fetch FETCH_SIZE GRBM_GUI_ACTIVE
-pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+for wl in cfg3 cfg2 cfg3_f32 cfg4 cfg5; do
+  pmc $wl fetch FETCH_SIZE
+  pmc $wl valu SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD
+done
+pmc cfg3 sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_ANY
+pmc cfg3 sq2 SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VALU
+pmc cfg3 tcp TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum
+pmc cfg3 tcc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum
+python tools/prof_collect.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
