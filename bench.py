@@ -138,14 +138,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: the RCCL path is then exercised)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
@@ -186,7 +187,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -215,7 +216,7 @@ def main():
         e2e_ms = sorted(e2e)[len(e2e) // 2]
         # final gather of the finished frames (the only collective of the job)
         gather_ms = None
-        if world > 1:
+        if use_dist:
             frames = torch.cat([out["color"], out["depth"]] + ([out["T"]] if want_T else []), dim=1)
             buf = torch.empty((world,) + tuple(frames.shape), device=dev)
             fence()
@@ -226,7 +227,7 @@ def main():
 
     kern_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
     t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
 
@@ -291,7 +292,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

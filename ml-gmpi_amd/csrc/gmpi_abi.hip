@@ -259,12 +259,15 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     int variant = params->variant;
     if (variant == GMPI_VARIANT_AUTO) {
-        // Measured on MI355X (profiles/r02_variants.txt): the tile kernel wins on large launches (C3-C5: 32 waves per CU hide
-        // its latencies, its shared 32x16 boxes tolerate tilted cameras); the strip kernel wins when the launch under-fills
-        // the chip (C2: 8 views of 256^2 = 2 K pixels per CU: 4 pixels per lane need a quarter of the waves)
+        // Measured on MI355X (profiles/r02_variants.txt): the tile kernel wins on large launches (configs 3-5: 32 waves per CU
+        // hide its latencies, its shared 32x16 boxes tolerate tilted cameras); the strip kernel wins when the launch under-fills
+        // the chip (config 2, 8 views of 256^2: 4 pixels per lane need a quarter of the waves; single small views: its waves
+        // split the planes).  Strict-order mode has no plane split: there only launches of 2^18 .. 2^19 pixels go to it.
         const int64_t pixels = static_cast<int64_t>(p.N) * p.H * p.W;
+        const bool strict = (p.flags & GMPI_FLAG_STRICT_ORDER) != 0;
         const bool lds_ok = lds_variant_supports(p, params->rgba_dtype), wave_ok = wave_variant_supports(p, params->rgba_dtype);
-        variant = (wave_ok && (pixels <= (int64_t(1) << 20) || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
+        const bool small = pixels <= (int64_t(1) << 19) && (!strict || pixels > (int64_t(1) << 18));
+        variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
     }
     if (variant == GMPI_VARIANT_GATHER) {
         if (p.N > 65535) return GMPI_E_SHAPE;  // the gather kernel puts the view index in grid.z

@@ -108,14 +108,20 @@ __device__ __forceinline__ int wave_max(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <typename TexT, bool AC, bool STRICT, int WPB, int WPS>
-__global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParams p, const int tiles_x, const int tiles_y,
+// SPLIT > 1 (J1; launches that under-fill the chip): SPLIT wavefronts share a strip, each composites a
+// contiguous range of planes front to back, and the partial (C, Z, T) triples are merged IN PLANE ORDER with the associative
+// operator (C1, Z1, T1) (+) (C2, Z2, T2) = (C1 + T1 C2, Z1 + T1 Z2, T1 T2) of mpi.py:421-434 -- through LDS and one workgroup
+// barrier at the very end (the partials live in different wavefronts).  Default mode only: the strict-order mode keeps the
+// reference's sequential association (the two differ by rounding, ~1e-7).
+template <typename TexT, bool AC, bool STRICT, int WPB, int WPS, int SPLIT>
+__global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(const KParams p, const int tiles_x, const int tiles_y,
                                                                    const int n_tiles) {
     using IO = ItemIO<TexT>;
     constexpr int TPI = IO::kTPI;
     constexpr int ES = static_cast<int>(sizeof(TexT));
     constexpr int kWaveLds = wave_lds(WPS), kBoxSlots = box_slots(WPS);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[WPB * kWaveLds];
+    static_assert(SPLIT == 1 || !STRICT, "plane split changes the association of the composite");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[WPB * SPLIT * kWaveLds];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
@@ -161,9 +167,18 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
         if (behind) atomicOr(p.status, 4u);
     }
 
-    // ---- this wave's strip (there is no workgroup barrier in this kernel: a strip past the right edge just leaves) ----
-    const int sx0 = (txi * WPB + wv) * kSW, sy0 = tyi * kSH;
-    if (sx0 >= W) return;
+    // ---- this wave's strip and plane range (no workgroup barrier on the data path; with SPLIT > 1 one at the very end, so a
+    //      strip past the right edge stays as a ghost that does nothing but reach it) ----
+    const int part = SPLIT == 1 ? 0 : wv / WPB;  // which range of planes
+    int sx0 = (txi * WPB + (wv - part * WPB)) * kSW;
+    const int sy0 = tyi * kSH;
+    const bool ghost = sx0 >= W;
+    if (ghost) {
+        if (SPLIT == 1) return;
+        sx0 = 0;
+    }
+    const int planes_per_part = (D + SPLIT - 1) / SPLIT;
+    const int k_begin = SPLIT == 1 ? 0 : min(part * planes_per_part, D), k_end = SPLIT == 1 ? D : min(k_begin + planes_per_part, D);
     const int lxp = lane & 31, lyp = lane >> 5;
     const int pxx = min(sx0 + lxp, W - 1);
     float rx[kPX], ry[kPX], rz[kPX], rrz[kPX];
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
     // cameras shear the box); a half that still does not fit (textures much finer than the image, degenerate rays) takes
     // the direct gather.  Everything below is wave-uniform control flow.
 #pragma unroll 1
-    for (int att = 0; att < 3; ++att) {
+    for (int att = 0; att < 3 && !ghost && k_begin < k_end; ++att) {
         const int pmask = att == 0 ? 3 : att;  // pixel pairs this pass composites
         const int y_lo = min(sy0 + (att == 2 ? kSH / 2 : 0), H - 1);
         const int y_hi = min(sy0 + (att == 1 ? kSH / 2 - 1 : kSH - 1), H - 1);
@@ -242,8 +257,8 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
         // inside or outside the texture (zeros padding by one compare per item).  fp32 volumes: multiples of 4 texels.
         constexpr int kLooseAlign = ES == 2 ? 2 : TPI;
         int ni_loose = 1, ni_tight = 1, nr_max = 1, touch = 0;
-        for (int g = 0; g < D; g += 16) {
-            const Box b = box_of(min(g + qt, D - 1));
+        for (int g = k_begin; g < k_end; g += 16) {
+            const Box b = box_of(min(g + qt, k_end - 1));
             if (b.bx1 < b.bx0) ni_loose = ni_tight = 1 << 20;
             ni_loose = max(ni_loose, (b.bx1 - (b.bx0 & ~(kLooseAlign - 1))) / TPI + 1);
             ni_tight = max(ni_tight, (b.bx1 - (b.bx0 & ~(TPI - 1))) / TPI + 1);
@@ -277,11 +292,11 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
         // hi = {w/2, h/2, RN(1/(w/2)), RN(1/(h/2))}
         auto fill = [&](int k0) {
             const int k = k0 + qt;
-            const Box b = box_of(min(k, D - 1));
+            const Box b = box_of(min(k, k_end - 1));
             // correctly rounded reciprocals of the plane's half extents (div_by_recip needs RN(1/d)): one IEEE division per lane
             const float rv = 1.0f / ((qc & 1) ? b.hh : b.hw);
             const float ro = __shfl_xor(rv, 1);
-            if (qc == 0 && k < D) {
+            if (qc == 0 && k < k_end) {
                 const int qx0 = b.bx0 & ~(align - 1), ni = (b.bx1 - qx0) / TPI + 1;
                 const int clo = min(max(-qx0 / TPI, 0), ni), chi = min(max((Wt - qx0) / TPI, 0), ni);  // inside the texture AND the plane's box
                 const int origin = (b.by0 * static_cast<int>(s_row) + qx0) * ES;
@@ -307,12 +322,13 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
             auto tap_ptr = [&](uint32_t base, int idx) {
                 return reinterpret_cast<const lds_f32x4*>(static_cast<uintptr_t>(base + 16u * static_cast<uint32_t>(idx)));
             };
+            constexpr int GRP = WPS >= 4 ? 1 : 2;  // pixels whose taps are in flight together (128 / 168 VGPRs)
 #pragma unroll
-            for (int jp = 0; jp < kPX; jp += 2) {
+            for (int jp = 0; jp < kPX; jp += GRP) {
                 if (!(pmask & (1 << (jp / 2)))) continue;
                 if constexpr (STRICT) {
 #pragma unroll
-                    for (int j = jp; j < jp + 2; ++j) {
+                    for (int j = jp; j < jp + GRP; ++j) {
                         float s, ix, iy, u, v, smp[4];
                         plane_coord<AC>(zdiff, hh + hh, hw + hw, ex, ey, rx[j], ry[j], rz[j], cx, cy, ix, iy, s, u, v);
                         const Footprint f = footprint(ix, iy, Ht, Wt);
@@ -325,10 +341,10 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
                         blend<true>(A[j], smp[0], smp[1], smp[2], smp[3], s, ray_dot(j));
                     }
                 } else {
-                    float s[2], fx[2], fy[2];  // (the four weights are formed after the reads: 2 live values per pixel, not 4)
-                    f32x4_t q_nw[2], q_ne[2], q_sw[2], q_se[2];
+                    float s[GRP], fx[GRP], fy[GRP];  // (the four weights are formed after the reads: 2 live values per pixel, not 4)
+                    f32x4_t q_nw[GRP], q_ne[GRP], q_sw[GRP], q_se[GRP];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < GRP; ++h) {
                         const int j = jp + h;
                         float ix, iy;
                         plane_coord_recip<AC>(zdiff, hw, hh, rw, rh, ex, ey, rx[j], ry[j], rz[j], rrz[j], cx, cy, ix, iy, s[h]);
@@ -339,7 +355,7 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
                         q_nw[h] = t0[0], q_ne[h] = t0[1], q_sw[h] = t1[0], q_se[h] = t1[1];
                     }
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < GRP; ++h) {
                         const int j = jp + h;
                         const float gx = 1.0f - fx[h], gy = 1.0f - fy[h];
                         const float w_nw = gx * gy, w_ne = fx[h] * gy, w_sw = gx * fy[h], w_se = fx[h] * fy[h];
@@ -466,16 +482,16 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
                                 if (IO::bad(L[q][c])) bad |= 2u;
                     }
                 };
-                fill(0);
-                issue(0);
+                fill(k_begin);
+                issue(k_begin);
 #pragma unroll 1
-                for (int g0 = 0; g0 < D; g0 += kGroup) {
-                    if (g0 + kGroup < D) fill(g0 + kGroup);  // the slots of planes [g0 - 16, g0) are consumed
-                    const int g1 = min(g0 + kGroup, D);
+                for (int g0 = k_begin; g0 < k_end; g0 += kGroup) {
+                    if (g0 + kGroup < k_end) fill(g0 + kGroup);  // the slots of planes [g0 - 16, g0) are consumed
+                    const int g1 = min(g0 + kGroup, k_end);
 #pragma unroll 1
                     for (int k = g0; k < g1; ++k) {
                         stage(k);                  // box of plane k -> LDS (after this wave's reads of plane k-1: LDS is in order)
-                        issue(min(k + 1, D - 1));  // in flight while plane k is composited
+                        issue(min(k + 1, k_end - 1));  // in flight while plane k is composited
 #ifdef GMPI_TUNE
                         if (p.flags & (1u << 25)) continue;  // ablation: loader only
 #endif
@@ -490,7 +506,7 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
             }
         } else {
             // ---- direct gather (boxes do not fit): same arithmetic as render_gather.hip ----
-            for (int k = 0; k < D; ++k) {
+            for (int k = k_begin; k < k_end; ++k) {
                 const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
                 const float zdiff = d - ez;
 #pragma unroll
@@ -504,6 +520,38 @@ __global__ __launch_bounds__(WPB * 64, WPS) void render_wave_kernel(const KParam
             }
         }
         if (att == 0) break;
+    }
+
+    // ---- merge of the plane ranges (SPLIT > 1): parts 1 .. SPLIT-1 hand their (T, C, Z) over through their own LDS region,
+    //      part 0 folds them in plane order ----
+    if constexpr (SPLIT > 1) {
+        float* const mine = reinterpret_cast<float*>(smem + wv * kWaveLds);
+        if (part > 0) {
+#pragma unroll
+            for (int j = 0; j < kPX; ++j) {
+                const float v[5] = {A[j].T, A[j].r, A[j].g, A[j].b, A[j].z};
+#pragma unroll
+                for (int c = 0; c < 5; ++c) mine[(j * 5 + c) * 64 + lane] = v[c];
+            }
+        }
+        __syncthreads();
+        if (part > 0 || ghost) {
+            report_status(p.status, bad);
+            return;
+        }
+#pragma unroll 1
+        for (int q = 1; q < SPLIT; ++q) {
+            const float* theirs = reinterpret_cast<const float*>(smem + (wv + q * WPB) * kWaveLds);
+#pragma unroll
+            for (int j = 0; j < kPX; ++j) {
+                const float T2 = theirs[(j * 5 + 0) * 64 + lane];
+                A[j].r = __builtin_fmaf(A[j].T, theirs[(j * 5 + 1) * 64 + lane], A[j].r);
+                A[j].g = __builtin_fmaf(A[j].T, theirs[(j * 5 + 2) * 64 + lane], A[j].g);
+                A[j].b = __builtin_fmaf(A[j].T, theirs[(j * 5 + 3) * 64 + lane], A[j].b);
+                A[j].z = __builtin_fmaf(A[j].T, theirs[(j * 5 + 4) * 64 + lane], A[j].z);
+                A[j].T = A[j].T * T2;
+            }
+        }
     }
 
     // ---- epilogue ----
@@ -546,32 +594,49 @@ bool wave_variant_supports(const KParams& p, int dtype) {
     return true;
 }
 
-template <typename TexT, int WPB, int WPS>
+template <typename TexT, int WPB, int WPS, int SPLIT>
 static hipError_t launch_wave_t(const KParams& p, hipStream_t stream) {
     const int tiles_x = (p.W + WPB * kSW - 1) / (WPB * kSW), tiles_y = (p.H + kSH - 1) / kSH;
     const int n_tiles = tiles_x * tiles_y * p.N;
-    const dim3 grid(((n_tiles + 7) / 8) * 8), block(WPB * 64);
+    const dim3 grid(((n_tiles + 7) / 8) * 8), block(WPB * SPLIT * 64);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
-    if (ac && strict) hipLaunchKernelGGL((render_wave_kernel<TexT, true, true, WPB, WPS>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (ac) hipLaunchKernelGGL((render_wave_kernel<TexT, true, false, WPB, WPS>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (strict) hipLaunchKernelGGL((render_wave_kernel<TexT, false, true, WPB, WPS>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else hipLaunchKernelGGL((render_wave_kernel<TexT, false, false, WPB, WPS>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    if constexpr (SPLIT == 1) {
+        if (ac && strict) hipLaunchKernelGGL((render_wave_kernel<TexT, true, true, WPB, WPS, 1>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+        else if (!ac && strict) hipLaunchKernelGGL((render_wave_kernel<TexT, false, true, WPB, WPS, 1>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    }
+    if (ac && !strict) hipLaunchKernelGGL((render_wave_kernel<TexT, true, false, WPB, WPS, SPLIT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else if (!ac && !strict) hipLaunchKernelGGL((render_wave_kernel<TexT, false, false, WPB, WPS, SPLIT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
     return hipGetLastError();
+}
+
+template <int WPB, int WPS, int SPLIT>
+static hipError_t launch_wave_d(const KParams& p, int dtype, hipStream_t stream) {
+    switch (dtype) {
+        case 0: return launch_wave_t<float, WPB, WPS, SPLIT>(p, stream);
+        case 1: return launch_wave_t<bf16_t, WPB, WPS, SPLIT>(p, stream);
+        default: return launch_wave_t<f16_t, WPB, WPS, SPLIT>(p, stream);
+    }
 }
 
 hipError_t launch_wave(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
 #ifdef GMPI_TUNE
     p.flags |= static_cast<uint32_t>(tune & 0x700) << 16;  // 256: no memory traffic, 512: loader only, 1024: no LDS stores
+    if ((tune & 0xff) == 1) return launch_wave_d<4, 3, 1>(p, dtype, stream);
+    if ((tune & 0xff) == 2 && !(p.flags & (1u << 4))) return launch_wave_d<4, 3, 3>(p, dtype, stream);
+    if ((tune & 0xff) == 4 && !(p.flags & (1u << 4))) return launch_wave_d<2, 3, 6>(p, dtype, stream);
 #else
     (void)tune;
 #endif
-    // 4 strips side by side per workgroup (a 128x8 pixel band), 3 waves per SIMD (168 VGPRs, 13 KB of LDS per wave)
-    switch (dtype) {
-        case 0: return launch_wave_t<float, 4, 3>(p, stream);
-        case 1: return launch_wave_t<bf16_t, 4, 3>(p, stream);
-        default: return launch_wave_t<f16_t, 4, 3>(p, stream);
-    }
+    // 4 strips side by side per workgroup (a 128x8 pixel band), 3 waves per SIMD (168 VGPRs, 13 KB of LDS per wave).  A launch
+    // with fewer strips than the chip has wave slots (12 x 256) is latency-bound on the plane loop of each wave (~1 us per
+    // plane): SPLIT waves share a strip and its planes (default mode only; measured on MI355X, profiles/r02_variants.txt:
+    // one 256^2 x 96 view 190 us unsplit, 72 us 3-way, 45 us 6-way, against 75 us for the tile kernel).
+    const int64_t strips = static_cast<int64_t>(p.N) * ((p.W + kSW - 1) / kSW) * ((p.H + kSH - 1) / kSH);
+    const bool strict = p.flags & (1u << 4);
+    if (!strict && strips <= 512 && p.D >= 12) return launch_wave_d<2, 3, 6>(p, dtype, stream);
+    if (!strict && strips <= 1024 && p.D >= 6) return launch_wave_d<4, 3, 3>(p, dtype, stream);
+    return launch_wave_d<4, 3, 1>(p, dtype, stream);
 }
 
 }  // namespace gmpi

@@ -1,0 +1,72 @@
+"""Host side of `MPIRenderer.render()` under 8 concurrent processes (one per GPU of a node, run_gmpi.py:110 pattern): pose
+sampling (RNG-identical to the reference), camera tensors and the marshalling of GmpiRenderParams, with the library
+replaced by a recorder (no GPU here).  At 8 ranks the per-call host time must not grow by more than 1.5x over a single
+process: that -- not bandwidth -- is what decides whether view-sharded rendering scales."""
+import os
+import statistics
+import time
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+N_PROCS = 8
+CALLS = 80
+
+
+class _Recorder:
+    records_only = True
+
+    def __init__(self):
+        self.n = 0
+
+    def gmpi_mpi_render_launch(self, pref, stream):
+        self.n += 1
+        return 0
+
+    def gmpi_rgba_range_check_launch(self, *a):
+        return 0
+
+
+def _host_calls(rank, barrier, q):
+    import ml_gmpi_amd
+    from ml_gmpi_amd import _lib
+    rec = _Recorder()
+    _lib.load_library = lambda: rec
+    torch.manual_seed(rank)
+    B, D, S = 4, 8, 32
+    r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=D, device=torch.device("cpu"), ray_backend="torch", on_out_of_plane="raise")
+    rgba = torch.rand(B, D, 4, S, S)
+    with torch.no_grad():
+        for _ in range(5):
+            r.render(rgba, S, S)
+        if barrier is not None:
+            barrier.wait()
+        times = []
+        for _ in range(CALLS):
+            t0 = time.perf_counter()
+            r.render(rgba, S, S)
+            times.append(time.perf_counter() - t0)
+    assert rec.n == CALLS + 5
+    q.put((rank, statistics.median(times)))
+
+
+@pytest.mark.skipif(len(os.sched_getaffinity(0)) < N_PROCS, reason="needs 8 cores")
+def test_host_side_of_render_does_not_slow_down_with_8_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_host_calls, args=(0, None, q))
+    p.start()
+    _, alone = q.get(timeout=300)
+    p.join()
+    barrier = ctx.Barrier(N_PROCS)
+    procs = [ctx.Process(target=_host_calls, args=(r, barrier, q)) for r in range(N_PROCS)]
+    for p in procs:
+        p.start()
+    meds = [q.get(timeout=600)[1] for _ in procs]
+    for p in procs:
+        p.join()
+    together = statistics.median(meds)
+    print(f"host side of render(): {alone * 1e6:.0f} us alone, {together * 1e6:.0f} us median of 8 concurrent (worst {max(meds) * 1e6:.0f} us)")
+    assert together <= 1.5 * alone, (alone, meds)
+    assert max(meds) <= 2.5 * alone, (alone, meds)
