@@ -214,6 +214,18 @@ def main():
             torch.cuda.synchronize(dev)
             e2e.append((time.perf_counter() - t1) * 1e3)
         e2e_ms = sorted(e2e)[len(e2e) // 2]
+        # the same with the poses of the calls drawn ahead of time (MPIRenderer.prefetch_poses): what is left between two
+        # launches is the ray kernel, the marshalling of the parameter struct and the status read-back
+        r.prefetch_poses(8, n_views)
+        r.render(rgba, S, S, views_per_mpi=vpm)
+        e2e_pre = []
+        for _ in range(7):
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            r.render(rgba, S, S, views_per_mpi=vpm)
+            torch.cuda.synchronize(dev)
+            e2e_pre.append((time.perf_counter() - t1) * 1e3)
+        e2e_pre_ms = sorted(e2e_pre)[len(e2e_pre) // 2]
         # final gather of the finished frames (the only collective of the job)
         gather_ms = None
         if use_dist:
@@ -285,7 +297,7 @@ def main():
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": abytes,
                          # conservative companion: only the texel boxes the views actually touch
                          "footprint_bytes_per_launch": fbytes, "frac_footprint": round(fbytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "e2e_render_ms": round(e2e_ms, 3), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "e2e_render_ms": round(e2e_ms, 3), "e2e_render_prefetched_poses_ms": round(e2e_pre_ms, 3), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(preset, S, D, dtype, a.cpu_budget)

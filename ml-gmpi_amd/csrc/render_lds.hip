@@ -617,8 +617,6 @@ bool lds_variant_supports(const KParams& p, int dtype) {
 }
 
 constexpr int kTileW = 32;
-constexpr int kLayout16 = 1;  // default LDS layout of 16-bit volumes (see render_lds_kernel)
-constexpr int kLayout32 = 0;  // ... of fp32 volumes
 
 int lds_variant_query(int what) {
     switch (what) {
@@ -643,7 +641,11 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_lds(const KParams& p, int dtype, int tune, hipStream_t stream) {
+hipError_t launch_lds(const KParams& p0, int dtype, int tune, hipStream_t stream) {
+    KParams p = p0;
+#ifdef GMPI_TUNE  // profiling builds: GMPI_TUNE_WAVE + 256 no memory traffic, + 512 no compositing (loader only), + 1024 no LDS stores
+    p.flags |= static_cast<uint32_t>((tune >> 8) & 7) << 16;
+#endif
     // Shipped instances only: fp32 volumes keep fp32 planes in LDS (LAYOUT 0, 3 workgroups per CU), 16-bit volumes their raw
     // texels, interleaved (LAYOUT 1, 4 workgroups per CU); 32x16 pixel tiles, one plane of prefetch -- the values the round-1
     // ablations settled on (profiles/r01_ablation.txt; the other combinations are no longer instantiated).

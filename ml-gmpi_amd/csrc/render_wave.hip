@@ -1,29 +1,33 @@
-// render_wave.hip -- GMPI_VARIANT_WAVE: wave-private texel boxes, four pixels per lane.
+// render_wave.hip -- GMPI_VARIANT_WAVE, the strip kernel: wave-private texel boxes, four pixels per lane, plane split.
 //
-// Round-1's tile kernel (render_lds.hip) ran into two walls on MI355X (profiles/r01_ablation.txt):
-//   * VALU issue: 92-97 vector instructions per pixel*plane-wave, a third of them integer-class (16 shift/and per pixel to
-//     unpack 16-bit taps, loader predicates) which issue at ~4 cycles against ~2.8 for fp32 mul/add/fma;
-//   * the vector-L1 fill path: a 32-pixel-wide tile uses 33 % (16-bit) / 50 % (fp32) of the 128-byte lines it pulls.
+// The counters of round 1's tile kernel (render_lds.hip; profiles/r02_issue_budget.txt) show two walls on MI355X:
+//   * VALU issue: 98 vector instructions per wave and plane of 64 pixels, 40 % of them integer-class (16 shift/and per pixel to
+//     unpack 16-bit taps, loader, addresses) at 1.73 ns per instruction and SIMD against 1.24 ns for fp32 mul/add/fma;
+//   * the vector memory path: it holds a bounded number of wave-level load instructions per CU, the address unit takes a quad
+//     of lanes per clock whatever the width, and a 32-pixel-wide tile uses a third of each 128-byte line of a 16-bit volume.
 // This kernel is laid out for those two walls:
 //   * a wavefront owns a 32x8 pixel STRIP (4 pixels per lane: rows y, y+2, y+4, y+6) and stages the texel box of the strip
 //     privately: its own LDS region, its own prefetch registers, no workgroup barrier on the data path (LDS operations of
-//     one wave execute in order, so the box of plane k+1 may overwrite plane k's without any wait);
-//   * the 8 (or 4) waves of a workgroup own strips that lie SIDE BY SIDE (a 256x8 pixel band): their row segments are
-//     contiguous in memory, so the partial 128-byte lines at the seams are shared through the vector L1;
-//   * texels are stored in LDS as fp32 RGBA (16 bytes per texel, row pitch = box width): the storage->fp32 conversion is
-//     paid once per staged texel (~1.0-1.1 per pixel) by the loader instead of 16x per pixel by the compositor, a
-//     pixel's 16 taps are four ds_read_b128, and there is no unpack code in the compositor at all;
-//   * per pixel and plane the compositor spends 52 vector instructions (47 of them fp32-class): the exact coordinate
-//     chain (17), v_fract/v_cvt_flr for weights and indices (6), 4 weights, 3 address ops, 16 bilinear, 6 blend;
+//     one wave execute in order, so the box of plane k+1 may overwrite plane k's without any wait); 4 strips side by side per
+//     workgroup, 12 waves per CU (168 VGPRs, 13 KB of LDS each);
+//   * texels are stored in LDS as fp32 RGBA (16 bytes per texel): the storage->fp32 conversion is paid once per staged texel
+//     (~1.1-1.3 per pixel) by the loader instead of 16x per pixel by the compositor, a pixel's 16 taps are four
+//     ds_read_b128, and there is no unpack code in the compositor at all: 54 vector instructions per pixel and plane (the
+//     exact coordinate chain 17, v_fract / v_cvt_flr 4, weights 6, tap address 5, bilinear 16, blend 9, minus shared ones);
+//   * 16-byte loads (8 half-precision / 4 fp32 texels of each of the four channel images per lane) at dword alignment:
+//     4 load instructions per wave and plane, boxes as tight as the footprint (32 texels per row);
+//   * LDS rows are padded by one slot per 8 texture columns (holding a copy of the next texel), which makes the 16-byte
+//     stores of a wave conflict-free (lanes 9 slots apart) while the compositor still reads slot and slot + 1;
 //   * everything that is uniform per plane (box origin, texture bounds, LDS address constant, plane constants and their
-//     correctly rounded reciprocals) is computed by ONE lane per plane, 32 planes at a time, into a 64-entry ring in the
-//     wave's LDS region and read back as two 16-byte broadcasts per plane;
-//   * texture bounds along y are left to the buffer range check (descriptor = one channel image of the plane: rows
-//     above/below it produce offsets outside num_records and read as the zeros F.grid_sample's padding wants); only the
-//     x test is explicit, once per plane.
+//     correctly rounded reciprocals) is computed by one lane per plane and corner, 16 planes per round, into a 32-entry ring
+//     in the wave's LDS region and read back as two 16-byte broadcasts per plane;
+//   * texture bounds along y are left to the buffer range check (one descriptor per channel image -- on gfx950 the scalar
+//     offset of a buffer load takes part in the range check, so it cannot carry the channel): rows above/below the image
+//     read as the zeros F.grid_sample's padding wants; only the x test is explicit, once per plane.
 // The loader's lane -> (row, item) map is fixed per wave from the largest box over all planes, so the number of passes NP
-// is a compile-time constant of the plane loop (one instance per NP = 1..6).  A strip whose boxes do not fit (strongly
-// tilted views, textures much finer than the image, degenerate rays) takes the direct gather -- same arithmetic.
+// is a compile-time constant of the plane loop (one instance per NP = 1..3).  A strip whose boxes do not fit its LDS region
+// (tilted views) is rendered as its upper and lower half in two passes; a half that still does not fit (textures much finer
+// than the image, degenerate rays) takes the direct gather -- same arithmetic.
 //
 // Arithmetic contract: STRICT = op-for-op oracle/mpi_oracle.c (IEEE divisions, no FMA) -> bit-identical results.
 // Default: the three divisions through correctly rounded reciprocals (div_by_recip, gmpi_device.hpp), FMA blend,

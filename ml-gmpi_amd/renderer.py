@@ -88,6 +88,7 @@ class MPIRenderer:
         self.ray_backend = ray_backend
         self._batched_cam = None
         self._dhw_dev = None
+        self._pose_queue = []  # (key, yaws, pitches, c2w on the device): see prefetch_poses
         self.compute_mpi_spatial_volume()
         self.use_xyz_ztype = use_xyz_ztype
         self.use_normalized_xyz = use_normalized_xyz
@@ -205,12 +206,17 @@ class MPIRenderer:
         """(yaws [B,1], pitches [B,1], c2w [B,4,4] f32 on device, lists of ray_dir [1,3,H,W], eye [1,3], z_dir [1,3])
         -- mpi_renderer.py:337-385.  Poses are sampled on the host with the reference's RNG consumption;
         rays are rotated per view on `self.device` with torch.matmul, like the reference."""
-        c2w, yaws, pitches = gen_sphere_path(
-            n_cams=batch_size, sphere_center=self.sphere_center, sphere_r=self.sphere_r, yaw_mean=horizontal_mean,
-            yaw_std=horizontal_std, pitch_mean=vertical_mean, pitch_std=vertical_std,
-            n_truncated_stds=self.cam_pose_n_truncated_stds, flag_rnd=random_pose,
-            sample_method=self.cam_sample_method, given_yaws=given_yaws, given_pitches=given_pitches)
-        batch_tf_c2w = (c2w if isinstance(c2w, torch.Tensor) else torch.FloatTensor(c2w)).to(self.device)
+        key = self._pose_key(batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std, random_pose)
+        if given_yaws is None and given_pitches is None and self._pose_queue and self._pose_queue[0][0] == key:
+            _, yaws, pitches, batch_tf_c2w = self._pose_queue.pop(0)    # drawn ahead of time by prefetch_poses
+        else:
+            self._pose_queue.clear()                                     # a different request: the queue no longer applies
+            c2w, yaws, pitches = gen_sphere_path(
+                n_cams=batch_size, sphere_center=self.sphere_center, sphere_r=self.sphere_r, yaw_mean=horizontal_mean,
+                yaw_std=horizontal_std, pitch_mean=vertical_mean, pitch_std=vertical_std,
+                n_truncated_stds=self.cam_pose_n_truncated_stds, flag_rnd=random_pose,
+                sample_method=self.cam_sample_method, given_yaws=given_yaws, given_pitches=given_pitches)
+            batch_tf_c2w = (c2w if isinstance(c2w, torch.Tensor) else torch.FloatTensor(c2w)).to(self.device)
         if self.ray_backend == "hip":
             ray, eye, zd = self._generate_rays_hip(batch_tf_c2w)
             rays = [ray[i:i + 1] for i in range(ray.shape[0])]      # views of the batched tensors (no copies)
@@ -223,6 +229,34 @@ class MPIRenderer:
             r, e, z, _ = self.view_info_from_c2w_mat(self.cam, batch_tf_c2w[i, ...], device=self.device)
             rays.append(r), eyes.append(e), zdirs.append(z)
         return yaws, pitches, batch_tf_c2w, rays, eyes, zdirs
+
+    def _pose_key(self, batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std, random_pose):
+        return (int(batch_size), float(horizontal_mean), float(horizontal_std), float(vertical_mean), float(vertical_std),
+                bool(random_pose), self.cam_sample_method, float(self.cam_pose_n_truncated_stds))
+
+    def prefetch_poses(self, n_calls, batch_size, horizontal_mean=None, horizontal_std=None, vertical_mean=None,
+                       vertical_std=None, random_pose=True):
+        """Draws the camera poses of the next `n_calls` calls of `render()` / `sample_cam_poses()` (with these arguments) NOW:
+        the host work of a call (a dozen tiny CPU tensor ops, ~0.3 ms) then no longer sits between two kernel launches --
+        at C2 sizes it is longer than the kernel.  The torch RNG is consumed exactly as the calls themselves would have
+        consumed it, in the same order, so results are bit-identical as long as nothing else draws random numbers in
+        between; the matrices go to the device in one copy.  A call with different arguments discards what is left."""
+        hm = self.horizontal_mean if horizontal_mean is None else horizontal_mean
+        hs = self.horizontal_std if horizontal_std is None else horizontal_std
+        vm = self.vertical_mean if vertical_mean is None else vertical_mean
+        vs = self.vertical_std if vertical_std is None else vertical_std
+        key = self._pose_key(batch_size, hm, hs, vm, vs, random_pose)
+        drawn = []
+        for _ in range(n_calls):
+            c2w, yaws, pitches = gen_sphere_path(
+                n_cams=batch_size, sphere_center=self.sphere_center, sphere_r=self.sphere_r, yaw_mean=hm, yaw_std=hs,
+                pitch_mean=vm, pitch_std=vs, n_truncated_stds=self.cam_pose_n_truncated_stds, flag_rnd=random_pose,
+                sample_method=self.cam_sample_method, given_yaws=None, given_pitches=None)
+            drawn.append((yaws, pitches, torch.FloatTensor(c2w)))
+        if not drawn:
+            return
+        all_c2w = torch.stack([d[2] for d in drawn]).to(self.device)     # one host-to-device copy
+        self._pose_queue = [(key, d[0], d[1], all_c2w[i]) for i, d in enumerate(drawn)]
 
     def _generate_rays_hip(self, c2w: torch.Tensor):
         """(ray_dir [B,3,H,W], eye_pos [B,3], z_dir [B,3]) for c2w [B,4,4] on the device -- one launch

@@ -125,3 +125,31 @@ def test_host_math_context_restores_the_intra_op_thread_count():
         b = poses.truncated_normal(8, 0.0, 0.3, 2)
     assert inner == 1 and torch.get_num_threads() == before
     assert torch.equal(a, b)
+
+
+def test_prefetched_poses_are_the_poses_the_calls_would_have_drawn():
+    """MPIRenderer.prefetch_poses: same RNG consumption, same order, same bits as drawing inside each call."""
+    import ml_gmpi_amd
+    r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=4, device=torch.device("cpu"), ray_backend="torch")
+    r.set_cam(r.cam_fov, 8, 8)
+    args = (3, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    torch.manual_seed(77)
+    seq = [r.sample_cam_poses(*args) for _ in range(4)]
+    after_seq = torch.rand(3)
+    torch.manual_seed(77)
+    r.prefetch_poses(4, 3)
+    after_pre = torch.rand(3)
+    assert torch.equal(after_seq, after_pre)
+    for want in seq:
+        got = r.sample_cam_poses(*args)
+        for a, b in zip(want[:3], got[:3]):
+            assert torch.equal(a, b)
+        assert all(torch.equal(a, b) for a, b in zip(want[3], got[3]))
+    assert not r._pose_queue
+    # a call with other arguments discards the queue and draws for itself
+    r.prefetch_poses(2, 3)
+    torch.manual_seed(5)
+    a = r.sample_cam_poses(2, 0.0, 0.1, 0.0, 0.1, True)
+    torch.manual_seed(5)
+    b = r.sample_cam_poses(2, 0.0, 0.1, 0.0, 0.1, True)
+    assert torch.equal(a[2], b[2]) and not r._pose_queue
