@@ -45,8 +45,9 @@ constexpr int kRing = 32;         // planes in the per-wave table ring
 constexpr int kGroup = 16;        // ... refilled this many at a time (one round of the quad-parallel box code)
 constexpr int kEntry = 32;        // bytes per table entry (two 16-byte broadcasts)
 // LDS bytes per wave: 16 waves per CU (4 per SIMD, <= 128 VGPRs) or 12 (3 per SIMD, <= 168 VGPRs) use all 160 KB
-constexpr int wave_lds(int waves_per_simd) { return waves_per_simd >= 4 ? 10240 : 13312; }
-constexpr int box_slots(int waves_per_simd) { return (wave_lds(waves_per_simd) - kRing * kEntry) / 16 - 1; }  // fp32 RGBA texels (+ 1 slot of front padding)
+constexpr int wave_lds(int waves_per_simd) { return waves_per_simd >= 4 ? 10240 : waves_per_simd == 3 ? 13312 : 20480; }
+// texel slots of a wave's box: 16 bytes (fp32 RGBA) or 8 bytes (fp16 RGBA, HALF); 16 bytes of front padding
+constexpr int box_slots(int waves_per_simd, int slot_bytes) { return (wave_lds(waves_per_simd) - kRing * kEntry - 16) / slot_bytes; }
 constexpr int kMaxNP = 3;
 constexpr float kBoxSlack = 1.0f / 64;  // slack on the corner-derived box (fp32 error of ix is < 1e-3 texel)
 
@@ -55,6 +56,8 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) f32x4_t lds_f32x4;
 typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
+typedef __attribute__((address_space(3))) u32x2_t lds_u32x2;
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
 // One loader item = 16 bytes of one channel row = TPI texels (8 half-precision / 4 fp32): a wave-level load costs the
 // texture-address unit 16 cycles whatever its width (4 lanes per clock), so the loader moves 16 bytes per lane and load.
@@ -72,6 +75,8 @@ template <> struct ItemIO<float> {
         auto ok = [](uint32_t e) { return e <= 0x3f800000u || e == 0x80000000u; };
         return !(ok(v.x) && ok(v.y) && ok(v.z) && ok(v.w));
     }
+    static __device__ __forceinline__ void half_texels(const u32x4_t (&)[4], u32x4_t (&)[4]) {}  // (fp32 volumes are never staged as fp16)
+    static __device__ __forceinline__ bool unsafe_half(const u32x4_t&) { return false; }
 };
 template <uint32_t ONE> struct ItemIO16 {
     static constexpr int kTPI = 8;
@@ -87,7 +92,22 @@ template <uint32_t ONE> struct ItemIO16 {
         return !(ok2(v.x) && ok2(v.y) && ok2(v.z) && ok2(v.w));
     }
 };
+// HALF: the 8 texels of an item as fp16 RGBA (two dwords per texel: R|G<<16, B|A<<16) from the four channel vectors.
+//   bf16 -> fp16 through fp32 (v_cvt_pkrtz_f16_f32; exact for 2^-17 <= |v| <= 65280, below that truncated by < 2^-24);
+//   values that fp16 cannot hold are caught by unsafe_half() and that plane is composited by the direct gather.
 template <> struct ItemIO<bf16_t> : ItemIO16<0x3f80u> {
+    static __device__ __forceinline__ void half_texels(const u32x4_t (&L)[4], u32x4_t (&o)[4]) {  // o[i] = texels 2i (.xy), 2i+1 (.zw)
+        auto pk = [](uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__uint_as_float(a), __uint_as_float(b))); };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i].x = pk(L[0][i] << 16, L[1][i] << 16), o[i].y = pk(L[2][i] << 16, L[3][i] << 16);
+            o[i].z = pk(L[0][i] & 0xffff0000u, L[1][i] & 0xffff0000u), o[i].w = pk(L[2][i] & 0xffff0000u, L[3][i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ bool unsafe_half(const u32x4_t& v) {  // |v| > 65280 (the largest bf16 below fp16's maximum), inf, NaN
+        auto big = [](uint32_t d) { return (d & 0x7fffu) > 0x477fu || ((d >> 16) & 0x7fffu) > 0x477fu; };
+        return big(v.x) || big(v.y) || big(v.z) || big(v.w);
+    }
     static __device__ __forceinline__ void unpack(const u32x4_t& v, float (&o)[8]) {
         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -95,6 +115,14 @@ template <> struct ItemIO<bf16_t> : ItemIO16<0x3f80u> {
     }
 };
 template <> struct ItemIO<f16_t> : ItemIO16<0x3c00u> {
+    static __device__ __forceinline__ void half_texels(const u32x4_t (&L)[4], u32x4_t (&o)[4]) {  // verbatim: two v_perm_b32 per texel
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i].x = __builtin_amdgcn_perm(L[1][i], L[0][i], 0x05040100u), o[i].y = __builtin_amdgcn_perm(L[3][i], L[2][i], 0x05040100u);
+            o[i].z = __builtin_amdgcn_perm(L[1][i], L[0][i], 0x07060302u), o[i].w = __builtin_amdgcn_perm(L[3][i], L[2][i], 0x07060302u);
+        }
+    }
+    static __device__ __forceinline__ bool unsafe_half(const u32x4_t&) { return false; }
     static __device__ __forceinline__ void unpack(const u32x4_t& v, float (&o)[8]) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
@@ -117,14 +145,17 @@ __device__ __forceinline__ int wave_max(int v) {
 // operator (C1, Z1, T1) (+) (C2, Z2, T2) = (C1 + T1 C2, Z1 + T1 Z2, T1 T2) of mpi.py:421-434 -- through LDS and one workgroup
 // barrier at the very end (the partials live in different wavefronts).  Default mode only: the strict-order mode keeps the
 // reference's sequential association (the two differ by rounding, ~1e-7).
-template <typename TexT, bool AC, bool STRICT, int WPB, int WPS, int SPLIT>
+template <typename TexT, bool AC, bool STRICT, int WPB, int WPS, int SPLIT, bool HALF, int GRPSEL>
 __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(const KParams p, const int tiles_x, const int tiles_y,
                                                                    const int n_tiles) {
     using IO = ItemIO<TexT>;
     constexpr int TPI = IO::kTPI;
     constexpr int ES = static_cast<int>(sizeof(TexT));
-    constexpr int kWaveLds = wave_lds(WPS), kBoxSlots = box_slots(WPS);
+    constexpr int SS = HALF ? 8 : 16;  // bytes per texel slot in LDS
+    constexpr int PADS = HALF ? 2 : 1; // padding slots per 8 texture columns (lanes 80 / 144 bytes apart: conflict-free 16-byte stores)
+    constexpr int kWaveLds = wave_lds(WPS), kBoxSlots = box_slots(WPS, SS);
     static_assert(SPLIT == 1 || !STRICT, "plane split changes the association of the composite");
+    static_assert(!HALF || (!STRICT && sizeof(TexT) == 2), "fp16 texels in LDS: 16-bit volumes, default mode");
     __shared__ __attribute__((aligned(16))) unsigned char smem[WPB * SPLIT * kWaveLds];
 
     const int lane = threadIdx.x & 63;
@@ -281,12 +312,16 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
         // are 9 slots apart and rows 9 * LPR, so the slot of lane l is congruent to l modulo 8); the padding slot holds a
         // copy of the texel after it, so the compositor still reads slot and slot + 1.  (The copy of a row's first texel
         // lands in the last slot of the row above, which that phase leaves unused.)  Rows past the tallest box are not staged.
-        const int pitch = TPI == 8 ? 9 * LPR : TPI * LPR + (TPI * LPR + 7) / 8 + 1;  // slots per box row
+        const int pitch = TPI == 8 ? (8 + PADS) * LPR : TPI * LPR + (TPI * LPR + 7) / 8 + 1;  // slots per box row
         const bool fit = !wide && NP <= kMaxNP && pitch * NR <= kBoxSlots;
 #ifdef GMPI_TUNE
         if (p.status != nullptr && lane == 0) {  // debug: passes per strip / strips that end in the gather
-            if (att == 1) atomicAdd(p.status + 2, 1u);
-            if (att > 0 && !fit) atomicAdd(p.status + 3, 1u);
+            if (p.flags & (1u << 27)) {  // sums over the strips: extra passes, lanes per row, rows
+                if (fit) atomicAdd(p.status + 1, static_cast<uint32_t>(NP - 1)), atomicAdd(p.status + 2, static_cast<uint32_t>(LPR)), atomicAdd(p.status + 3, static_cast<uint32_t>(NR));
+            } else {
+                if (att == 1) atomicAdd(p.status + 2, 1u);
+                if (att > 0 && !fit) atomicAdd(p.status + 3, 1u);
+            }
         }
 #endif
         if (att == 0 && !fit) continue;  // try the halves
@@ -304,7 +339,7 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                 const int qx0 = b.bx0 & ~(align - 1), ni = (b.bx1 - qx0) / TPI + 1;
                 const int clo = min(max(-qx0 / TPI, 0), ni), chi = min(max((Wt - qx0) / TPI, 0), ni);  // inside the texture AND the plane's box
                 const int origin = (b.by0 * static_cast<int>(s_row) + qx0) * ES;
-                const uint32_t cst = box_addr - 16u * static_cast<uint32_t>(b.by0 * pitch + qx0 + (qx0 >> 3));
+                const uint32_t cst = box_addr - static_cast<uint32_t>(SS) * static_cast<uint32_t>(b.by0 * pitch + qx0 + PADS * (qx0 >> 3));
                 const int phase = qx0 & 7;  // position of the box origin inside its 8-column block (where the padding slots fall)
                 u32x4_t lo, hi;
                 lo.x = static_cast<uint32_t>(origin), lo.y = static_cast<uint32_t>(clo | (chi - clo) << 8 | phase << 16 | b.nr << 24), lo.z = cst,
@@ -318,18 +353,22 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
         // ---- compositing of one plane, taps from the wave's LDS box.  Two pixels at a time: both coordinate chains, then all 8
         //      tap reads, then the arithmetic -- half as many waits for LDS data as one pixel at a time, at 32 registers of taps
         //      (all four pixels at once, 64 registers of taps, measured slower: 1.32 vs 1.19 ms) ----
-        auto composite = [&](int k) {
+        auto composite = [&](int k, auto full_tag) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;  // all four pixels of a lane (compile time: no per-pixel branches)
             const u32x4_t lo = tab[2 * (k & (kRing - 1))], hi = tab[2 * (k & (kRing - 1)) + 1];
             const float zdiff = __uint_as_float(lo.w), hw = __uint_as_float(hi.x), hh = __uint_as_float(hi.y);
             const float rw = __uint_as_float(hi.z), rh = __uint_as_float(hi.w);
-            const uint32_t cst = lo.z, cst2 = lo.z + 16u * static_cast<uint32_t>(pitch);
+            const uint32_t row_bytes = static_cast<uint32_t>(SS) * static_cast<uint32_t>(pitch);
+            const uint32_t cst = lo.z, cst2 = lo.z + row_bytes;
             auto tap_ptr = [&](uint32_t base, int idx) {
                 return reinterpret_cast<const lds_f32x4*>(static_cast<uintptr_t>(base + 16u * static_cast<uint32_t>(idx)));
             };
-            constexpr int GRP = WPS >= 4 ? 1 : 2;  // pixels whose taps are in flight together (128 / 168 VGPRs)
+            // pixels whose taps are in flight together: 2 (32 registers of fp32 taps, 16 of fp16 taps; 4 pixels measured slower with
+            // either texel type), 1 in the 128-VGPR build
+            constexpr int GRP = GRPSEL > 0 ? GRPSEL : WPS >= 4 ? 1 : 2;
 #pragma unroll
             for (int jp = 0; jp < kPX; jp += GRP) {
-                if (!(pmask & (1 << (jp / 2)))) continue;
+                if (!FULL && GRP <= 2 && !(pmask & (1 << (jp / 2)))) continue;
                 if constexpr (STRICT) {
 #pragma unroll
                     for (int j = jp; j < jp + GRP; ++j) {
@@ -345,31 +384,55 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                         blend<true>(A[j], smp[0], smp[1], smp[2], smp[3], s, ray_dot(j));
                     }
                 } else {
+                    using TapT = std::conditional_t<HALF, u32x2_t, f32x4_t>;
                     float s[GRP], fx[GRP], fy[GRP];  // (the four weights are formed after the reads: 2 live values per pixel, not 4)
-                    f32x4_t q_nw[GRP], q_ne[GRP], q_sw[GRP], q_se[GRP];
+                    TapT q_nw[GRP], q_ne[GRP], q_sw[GRP], q_se[GRP];
 #pragma unroll
                     for (int h = 0; h < GRP; ++h) {
                         const int j = jp + h;
+                        if (!FULL && GRP > 2 && !(pmask & (1 << (j / 2)))) continue;
                         float ix, iy;
                         plane_coord_recip<AC>(zdiff, hw, hh, rw, rh, ex, ey, rx[j], ry[j], rz[j], rrz[j], cx, cy, ix, iy, s[h]);
                         fx[h] = __builtin_amdgcn_fractf(ix), fy[h] = __builtin_amdgcn_fractf(iy);
                         const int lx = floor_to_int(ix);
-                        const int idx = __mul24(floor_to_int(iy), pitch) + lx + (lx >> 3);
-                        const lds_f32x4 *t0 = tap_ptr(cst, idx), *t1 = tap_ptr(cst2, idx);
-                        q_nw[h] = t0[0], q_ne[h] = t0[1], q_sw[h] = t1[0], q_se[h] = t1[1];
+                        if constexpr (HALF) {
+                            // slot = y * pitch + x + 2 * (x >> 3): v_ashrrev, v_lshl_add, v_mad_i32_i24, v_lshl_add, v_add
+                            const int idx = __mul24(floor_to_int(iy), pitch) + (((lx >> 3) << 1) + lx);
+                            const uint32_t a0 = cst + (static_cast<uint32_t>(idx) << 3);
+                            const lds_u32x2 *t0 = reinterpret_cast<const lds_u32x2*>(static_cast<uintptr_t>(a0)),
+                                            *t1 = reinterpret_cast<const lds_u32x2*>(static_cast<uintptr_t>(a0 + row_bytes));
+                            q_nw[h] = t0[0], q_ne[h] = t0[1], q_sw[h] = t1[0], q_se[h] = t1[1];
+                        } else {
+                            const int idx = __mul24(floor_to_int(iy), pitch) + lx + (lx >> 3);
+                            const lds_f32x4 *t0 = tap_ptr(cst, idx), *t1 = tap_ptr(cst2, idx);
+                            q_nw[h] = t0[0], q_ne[h] = t0[1], q_sw[h] = t1[0], q_se[h] = t1[1];
+                        }
                     }
 #pragma unroll
                     for (int h = 0; h < GRP; ++h) {
                         const int j = jp + h;
+                        if (!FULL && GRP > 2 && !(pmask & (1 << (j / 2)))) continue;
                         const float gx = 1.0f - fx[h], gy = 1.0f - fy[h];
                         const float w_nw = gx * gy, w_ne = fx[h] * gy, w_sw = gx * fy[h], w_se = fx[h] * fy[h];
                         float smp[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            float acc = q_nw[h][c] * w_nw;
-                            acc = __builtin_fmaf(q_ne[h][c], w_ne, acc);
-                            acc = __builtin_fmaf(q_sw[h][c], w_sw, acc);
-                            smp[c] = __builtin_fmaf(q_se[h][c], w_se, acc);
+                            if constexpr (HALF) {
+                                // fp16 -> fp32 inside the FMA (v_fma_mix_f32: the conversion is exact and free of a separate instruction)
+                                auto pick = [&](const u32x2_t& q) -> float {
+                                    const f16x2_t hv = __builtin_bit_cast(f16x2_t, c < 2 ? q.x : q.y);
+                                    return static_cast<float>((c & 1) ? hv.y : hv.x);
+                                };
+                                float acc = __builtin_fmaf(pick(q_nw[h]), w_nw, 0.0f);
+                                acc = __builtin_fmaf(pick(q_ne[h]), w_ne, acc);
+                                acc = __builtin_fmaf(pick(q_sw[h]), w_sw, acc);
+                                smp[c] = __builtin_fmaf(pick(q_se[h]), w_se, acc);
+                            } else {
+                                float acc = q_nw[h][c] * w_nw;
+                                acc = __builtin_fmaf(q_ne[h][c], w_ne, acc);
+                                acc = __builtin_fmaf(q_sw[h][c], w_sw, acc);
+                                smp[c] = __builtin_fmaf(q_se[h][c], w_se, acc);
+                            }
                         }
                         const float w = smp[3] * A[j].T;
                         A[j].r = __builtin_fmaf(w, smp[0], A[j].r);
@@ -383,6 +446,19 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                 }
             }
         };
+        // one plane straight from global memory (boxes that do not fit; planes holding a value fp16 cannot represent)
+        auto composite_gather = [&](int k) __attribute__((always_inline)) {
+            const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
+            const float zdiff = d - ez;
+#pragma unroll
+            for (int j = 0; j < kPX; ++j) {
+                if (!(pmask & (1 << (j / 2)))) continue;
+                float ix, iy, s, u, v, smp[4];
+                plane_coord<AC>(zdiff, ph, pw, ex, ey, rx[j], ry[j], rz[j], cx, cy, ix, iy, s, u, v);
+                gather_sample<TexT, STRICT>(vol + static_cast<int64_t>(k) * s_plane, s_chan, s_row, Ht, Wt, ix, iy, check_range, bad, smp);
+                blend<STRICT>(A[j], smp[0], smp[1], smp[2], smp[3], s, ray_dot(j));
+            }
+        };
 
         if (fit) {
             // ---- loader role of this lane: row lr + q * RPP, item column lc of the box ----
@@ -390,17 +466,20 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
             const bool lane_ok = lr < RPP;
             // slot of the lane's first texel x0 = qx0 + TPI * lc relative to the slot of qx0: TPI * lc + (x0 >> 3) - (qx0 >> 3);
             // for 8-texel items that is 9 * lc, for 4-texel items 4 * lc + ((lc + odd) >> 1) with odd = (qx0 / 4) & 1
-            const uint32_t dst0 = box_addr + 16u * static_cast<uint32_t>(lr * pitch + TPI * lc + (TPI == 8 ? lc : 0));
+            const uint32_t dst0 = box_addr + static_cast<uint32_t>(SS) * static_cast<uint32_t>(lr * pitch + TPI * lc + (TPI == 8 ? PADS * lc : 0));
             const bool row_ok_last = lr + (NP - 1) * RPP < NR;  // the last pass may reach past the tallest box
-            const uint32_t dst_step = 16u * static_cast<uint32_t>(RPP * pitch);
+            const uint32_t dst_step = static_cast<uint32_t>(SS) * static_cast<uint32_t>(RPP * pitch);
             const uint32_t goff0 = static_cast<uint32_t>((lr * static_cast<int>(s_row) + TPI * lc) * ES);
             const uint32_t goff_step = static_cast<uint32_t>(RPP * static_cast<int>(s_row) * ES);
             const int num_records = __builtin_amdgcn_readfirstlane(static_cast<int>(((Ht - 1) * s_row + Wt) * ES));
 
-            auto run = [&](auto np) {
+            auto run = [&](auto np, auto full_tag) -> int {
                 constexpr int NPC = decltype(np)::value;
-                u32x4_t L[NPC][4];  // the loads of the next plane, in flight while the current one is composited
-                auto issue = [&](int k) {
+                // the loads of the next plane, in flight while the current one is composited (a second plane of loads in flight
+                // was measured twice this round, with fp32 and with fp16 texels: no gain, profiles/r02_variants.txt)
+                using LoadRegs = u32x4_t[NPC][4];
+                LoadRegs La;
+                auto issue = [&](int k, LoadRegs& L) __attribute__((always_inline)) {
                     const u32x4_t lo = tab[2 * (k & (kRing - 1))];
                     const uint32_t clo = lo.y & 0xffu, ncol = (lo.y >> 8) & 0xffu, nrk = lo.y >> 24;
                     const bool xok = lane_ok & (static_cast<uint32_t>(lc) - clo < ncol);
@@ -427,8 +506,22 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                 };
                 // storage -> fp32, range check, and the 16-byte stores of one pass.  PH = phase of the box origin in its
                 // 8-column block (compile time: the slot offsets are immediates)
+                u32x4_t hpair[4];  // HALF: the item's texels as fp16 RGBA, two per vector (converted once, stored by the phase's pattern)
                 auto store_pass = [&](auto ph, uint32_t dst, bool dup, u32x4_t (&Lq)[4], uint32_t& mx) {
                     constexpr int PH = decltype(ph)::value;
+                    if constexpr (HALF) {
+                        // fp16 RGBA texels, 8 bytes each: texel t of the item sits in slot t + 2 * ((PH + t) >> 3) of the lane's
+                        // 10-slot window; the first padding slot after an 8-column block holds a copy of the block's successor
+                        // (so that slot, slot + 1 are always x, x + 1), the second is dead.  The window is written as five
+                        // slot pairs = 16-byte stores of the texel pairs P0..P3 as converted (PH is even): the pair that starts
+                        // a block is stored twice, once into the padding pair before it (copy + dead slot).
+                        lds_u32x4* d = reinterpret_cast<lds_u32x4*>(static_cast<uintptr_t>(dst));
+                        constexpr int HB = (8 - PH) / 2;  // first pair of the next 8-column block (4: this lane's pair 0 starts a block)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) d[i + (i >= HB ? 1 : 0)] = hpair[i];
+                        if (HB == 4) d[-1] = hpair[0];
+                        else d[HB] = hpair[HB];
+                    } else {
                     float ch[4][TPI];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -444,8 +537,9 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                         d[so] = tex;
                         if (TPI == 8 ? ((PH + t) & 7) == 0 : (t == 0 && dup)) d[so - 1] = tex;  // copy into the padding slot before an 8-column block
                     }
+                    }
                 };
-                auto stage = [&](int k) {
+                auto stage = [&](int k, LoadRegs& L) __attribute__((always_inline)) {
                     uint32_t mx = 0;
                     const uint32_t phase = __builtin_amdgcn_readfirstlane((tab[2 * (k & (kRing - 1))].y >> 16) & 7u);
                     uint32_t dstk = dst0;
@@ -464,6 +558,11 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                             continue;
                         }
 #endif
+                        if constexpr (HALF) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) mx = IO::fold(mx, L[q][c]);
+                            IO::half_texels(L[q], hpair);
+                        }
                         if (lane_ok && (q + 1 < NPC || row_ok_last)) {
                             const uint32_t dst = dstk + static_cast<uint32_t>(q) * dst_step;
                             if constexpr (TPI == 8) {
@@ -478,50 +577,61 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                             }
                         }
                     }
-                    if (check_range && __builtin_expect(IO::suspicious(mx), 0)) {
+                    bool unsafe = false;  // HALF: the plane holds a value fp16 cannot represent
+                    if ((check_range || HALF) && __builtin_expect(IO::suspicious(mx), 0)) {
 #pragma unroll
                         for (int q = 0; q < NPC; ++q)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                if (IO::bad(L[q][c])) bad |= 2u;
+                            for (int c = 0; c < 4; ++c) {
+                                if (check_range && IO::bad(L[q][c])) bad |= 2u;
+                                if (HALF && IO::unsafe_half(L[q][c])) unsafe = true;
+                            }
                     }
+                    return HALF && __any(unsafe);
                 };
                 fill(k_begin);
-                issue(k_begin);
+                issue(k_begin, La);
 #pragma unroll 1
                 for (int g0 = k_begin; g0 < k_end; g0 += kGroup) {
                     if (g0 + kGroup < k_end) fill(g0 + kGroup);  // the slots of planes [g0 - 16, g0) are consumed
                     const int g1 = min(g0 + kGroup, k_end);
 #pragma unroll 1
                     for (int k = g0; k < g1; ++k) {
-                        stage(k);                  // box of plane k -> LDS (after this wave's reads of plane k-1: LDS is in order)
-                        issue(min(k + 1, k_end - 1));  // in flight while plane k is composited
+                        const bool by_gather = stage(k, La);  // box of plane k -> LDS (after this wave's reads of plane k-1: LDS is in order)
+                        issue(min(k + 1, k_end - 1), La);  // in flight while plane k is composited
 #ifdef GMPI_TUNE
                         if (p.flags & (1u << 25)) continue;  // ablation: loader only
 #endif
-                        composite(k);
+                        // HALF: a plane holding a value fp16 cannot represent ends the staged loop; the caller composites the
+                        // rest of the planes by the direct gather (a side exit instead of a second path through the loop body:
+                        // no copies of the accumulators where two paths would merge)
+                        if (HALF && __builtin_expect(by_gather, 0)) return k;
+                        composite(k, full_tag);
                     }
                 }
+                return k_end;
             };
-            switch (NP) {
-                case 1: run(std::integral_constant<int, 1>{}); break;
-                case 2: run(std::integral_constant<int, 2>{}); break;
-                default: run(std::integral_constant<int, 3>{}); break;
+            int k_done = k_end;
+            if (att == 0) {  // the whole strip: the common case, no per-pixel predicates
+                switch (NP) {
+                    case 1: k_done = run(std::integral_constant<int, 1>{}, std::true_type{}); break;
+                    case 2: k_done = run(std::integral_constant<int, 2>{}, std::true_type{}); break;
+                    default: k_done = run(std::integral_constant<int, 3>{}, std::true_type{}); break;
+                }
+            } else {
+                switch (NP) {
+                    case 1: k_done = run(std::integral_constant<int, 1>{}, std::false_type{}); break;
+                    case 2: k_done = run(std::integral_constant<int, 2>{}, std::false_type{}); break;
+                    default: k_done = run(std::integral_constant<int, 3>{}, std::false_type{}); break;
+                }
+            }
+            if (HALF) {
+#pragma unroll 1
+                for (int k = k_done; k < k_end; ++k) composite_gather(k);
             }
         } else {
             // ---- direct gather (boxes do not fit): same arithmetic as render_gather.hip ----
-            for (int k = k_begin; k < k_end; ++k) {
-                const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
-                const float zdiff = d - ez;
-#pragma unroll
-                for (int j = 0; j < kPX; ++j) {
-                    if (!(pmask & (1 << (j / 2)))) continue;
-                    float ix, iy, s, u, v, smp[4];
-                    plane_coord<AC>(zdiff, ph, pw, ex, ey, rx[j], ry[j], rz[j], cx, cy, ix, iy, s, u, v);
-                    gather_sample<TexT, STRICT>(vol + static_cast<int64_t>(k) * s_plane, s_chan, s_row, Ht, Wt, ix, iy, check_range, bad, smp);
-                    blend<STRICT>(A[j], smp[0], smp[1], smp[2], smp[3], s, ray_dot(j));
-                }
-            }
+            for (int k = k_begin; k < k_end; ++k) composite_gather(k);
         }
         if (att == 0) break;
     }
@@ -598,48 +708,70 @@ bool wave_variant_supports(const KParams& p, int dtype) {
     return true;
 }
 
-template <typename TexT, int WPB, int WPS, int SPLIT>
+template <typename TexT, int WPB, int WPS, int SPLIT, bool HALF, int GRPSEL, bool STRICT>
 static hipError_t launch_wave_t(const KParams& p, hipStream_t stream) {
     const int tiles_x = (p.W + WPB * kSW - 1) / (WPB * kSW), tiles_y = (p.H + kSH - 1) / kSH;
     const int n_tiles = tiles_x * tiles_y * p.N;
     const dim3 grid(((n_tiles + 7) / 8) * 8), block(WPB * SPLIT * 64);
-    const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
-    if constexpr (SPLIT == 1) {
-        if (ac && strict) hipLaunchKernelGGL((render_wave_kernel<TexT, true, true, WPB, WPS, 1>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-        else if (!ac && strict) hipLaunchKernelGGL((render_wave_kernel<TexT, false, true, WPB, WPS, 1>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    }
-    if (ac && !strict) hipLaunchKernelGGL((render_wave_kernel<TexT, true, false, WPB, WPS, SPLIT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
-    else if (!ac && !strict) hipLaunchKernelGGL((render_wave_kernel<TexT, false, false, WPB, WPS, SPLIT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+#ifdef GMPI_FAST_BUILD  // experiment builds (tools/build_tune.sh -DGMPI_FAST_BUILD): align_corners only
+    if (!(p.flags & 1u)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((render_wave_kernel<TexT, true, STRICT, WPB, WPS, SPLIT, HALF, GRPSEL>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+#else
+    if (p.flags & 1u) hipLaunchKernelGGL((render_wave_kernel<TexT, true, STRICT, WPB, WPS, SPLIT, HALF, GRPSEL>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+    else hipLaunchKernelGGL((render_wave_kernel<TexT, false, STRICT, WPB, WPS, SPLIT, HALF, GRPSEL>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
+#endif
     return hipGetLastError();
 }
 
-template <int WPB, int WPS, int SPLIT>
-static hipError_t launch_wave_d(const KParams& p, int dtype, hipStream_t stream) {
+// Texel format in LDS: fp32 volumes and the strict-order mode stage fp32 RGBA (16 bytes per texel); 16-bit volumes in default
+// mode stage fp16 RGBA (HALF: 8 bytes per texel, the fp32 conversion folded into v_fma_mix_f32).
+template <int WPB, int WPS, int SPLIT, int GRPSEL = 0>
+static hipError_t launch_wave_d(const KParams& p, int dtype, hipStream_t stream, bool half = true) {
+    if (dtype == 0) return launch_wave_t<float, WPB, WPS, SPLIT, false, GRPSEL, false>(p, stream);
+#ifdef GMPI_TUNE
+    if (!half) return dtype == 1 ? launch_wave_t<bf16_t, WPB, WPS, SPLIT, false, 0, false>(p, stream) : launch_wave_t<f16_t, WPB, WPS, SPLIT, false, 0, false>(p, stream);
+#else
+    (void)half;
+#endif
+    return dtype == 1 ? launch_wave_t<bf16_t, WPB, WPS, SPLIT, true, GRPSEL, false>(p, stream) : launch_wave_t<f16_t, WPB, WPS, SPLIT, true, GRPSEL, false>(p, stream);
+}
+
+static hipError_t launch_wave_strict(const KParams& p, int dtype, hipStream_t stream) {  // one configuration: 4 strips per workgroup, unsplit
     switch (dtype) {
-        case 0: return launch_wave_t<float, WPB, WPS, SPLIT>(p, stream);
-        case 1: return launch_wave_t<bf16_t, WPB, WPS, SPLIT>(p, stream);
-        default: return launch_wave_t<f16_t, WPB, WPS, SPLIT>(p, stream);
+        case 0: return launch_wave_t<float, 4, 3, 1, false, 0, true>(p, stream);
+        case 1: return launch_wave_t<bf16_t, 4, 3, 1, false, 0, true>(p, stream);
+        default: return launch_wave_t<f16_t, 4, 3, 1, false, 0, true>(p, stream);
     }
 }
 
 hipError_t launch_wave(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
 #ifdef GMPI_TUNE
-    p.flags |= static_cast<uint32_t>(tune & 0x700) << 16;  // 256: no memory traffic, 512: loader only, 1024: no LDS stores
-    if ((tune & 0xff) == 1) return launch_wave_d<4, 3, 1>(p, dtype, stream);
-    if ((tune & 0xff) == 2 && !(p.flags & (1u << 4))) return launch_wave_d<4, 3, 3>(p, dtype, stream);
-    if ((tune & 0xff) == 4 && !(p.flags & (1u << 4))) return launch_wave_d<2, 3, 6>(p, dtype, stream);
+    p.flags |= static_cast<uint32_t>(tune & 0xf00) << 16;  // 256: no memory traffic, 512: loader only, 1024: no LDS stores, 2048: box statistics in status[1..3]
+    if (p.flags & (1u << 4)) return launch_wave_strict(p, dtype, stream);
+    switch (tune & 0xff) {
+        case 1: return launch_wave_d<4, 3, 1>(p, dtype, stream, false);   // fp32 texels in LDS (round 2's first strip kernel)
+        case 2: return launch_wave_d<4, 3, 3>(p, dtype, stream);
+        case 4: return launch_wave_d<2, 3, 6>(p, dtype, stream);
+        case 8: return launch_wave_d<4, 3, 1, 4>(p, dtype, stream);       // fp16 texels, 4 pixels of taps in flight
+        case 9: return launch_wave_d<4, 3, 1, 2>(p, dtype, stream);       // fp16 texels, 2 pixels (the shipped configuration)
+        case 25: return launch_wave_d<4, 2, 1, 2>(p, dtype, stream);      // 2 waves per SIMD (up to 256 VGPRs, 20 KB of LDS per wave)
+        default: break;
+    }
 #else
     (void)tune;
 #endif
     // 4 strips side by side per workgroup (a 128x8 pixel band), 3 waves per SIMD (168 VGPRs, 13 KB of LDS per wave).  A launch
     // with fewer strips than the chip has wave slots (12 x 256) is latency-bound on the plane loop of each wave (~1 us per
     // plane): SPLIT waves share a strip and its planes (default mode only; measured on MI355X, profiles/r02_variants.txt:
-    // one 256^2 x 96 view 190 us unsplit, 72 us 3-way, 45 us 6-way, against 75 us for the tile kernel).
+    // one 256^2 x 96 view 190 us unsplit, 72 us 3-way, 45 us 6-way, against 75 us for the tile kernel).  Between 1024 and 2048
+    // strips (at most 2 waves per SIMD, config 2) the split does not pay; the 2-waves-per-SIMD build (no register pressure:
+    // 213 VGPRs, no scratch) is 5-8 % faster there than the 168-VGPR one.
     const int64_t strips = static_cast<int64_t>(p.N) * ((p.W + kSW - 1) / kSW) * ((p.H + kSH - 1) / kSH);
-    const bool strict = p.flags & (1u << 4);
-    if (!strict && strips <= 512 && p.D >= 12) return launch_wave_d<2, 3, 6>(p, dtype, stream);
-    if (!strict && strips <= 1024 && p.D >= 6) return launch_wave_d<4, 3, 3>(p, dtype, stream);
+    if (p.flags & (1u << 4)) return launch_wave_strict(p, dtype, stream);  // strict order: sequential association, fp32 texels
+    if (strips <= 512 && p.D >= 12) return launch_wave_d<2, 3, 6>(p, dtype, stream);
+    if (strips <= 1024 && p.D >= 6) return launch_wave_d<4, 3, 3>(p, dtype, stream);
+    if (strips <= 2048) return launch_wave_d<4, 2, 1>(p, dtype, stream);
     return launch_wave_d<4, 3, 1>(p, dtype, stream);
 }
 

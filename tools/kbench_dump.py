@@ -1,0 +1,42 @@
+"""Dump the camera tensors of bench.py's cfg3 workload (and of a fixed-pose set) for tools/kbench.cpp, the torch-free kernel
+timing harness (a gpurun call without `import torch` costs seconds instead of minutes).  Runs on CPU.
+    python tools/kbench_dump.py  ->  gpurun_in/kb_<set>.bin   (not committed; travels with the snapshot)
+File: int32 N, S, D; float32 focal; float32 dhw[D,3], c2w[N,4,4] (rays are rebuilt by the harness: K^-1 [x+.5, y+.5, 1], normalised, rotated)."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ml_gmpi_amd
+
+S, D, B = 1024, 96, 4
+os.makedirs(os.path.join(ROOT, "gpurun_in"), exist_ok=True)
+r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=D, device=torch.device("cpu"), ray_backend="torch") if False else None
+from ml_gmpi_amd.renderer import MPIRenderer, PRESETS
+kw = dict(PRESETS["FFHQ"])
+kw.update(n_mpi_planes=D, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse", cam_sample_method="truncated_gaussian",
+          mpi_align_corners=True, use_confined_volume=True, device=torch.device("cpu"))
+r = MPIRenderer(**kw)
+r.set_cam(r.cam_fov, S, S)
+
+
+def dump(name, cam):
+    c2w, eye = cam[2].float().numpy(), torch.cat(cam[4]).float().numpy()
+    dhw = r.static_mpi_plane_dhws.reshape(-1, 3).float().numpy()
+    with open(os.path.join(ROOT, "gpurun_in", f"kb_{name}.bin"), "wb") as f:
+        np.array([c2w.shape[0], r.cam.height, D], dtype=np.int32).tofile(f)
+        np.array([r.cam.intrinsic_matrix[0, 0]], dtype=np.float32).tofile(f)
+        dhw.astype(np.float32).tofile(f); c2w.astype(np.float32).tofile(f)
+    print(name, c2w.shape, eye.tolist())
+
+
+torch.manual_seed(3)  # bench.py rank 0
+dump("bench", r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))
+gy = torch.tensor([[0.0], [0.15], [-0.3], [0.45]]); gp = torch.tensor([[0.0], [0.05], [0.1], [-0.2]])
+dump("fixed", r.sample_cam_poses(B, 0, 0, 0, 0, False, given_yaws=gy, given_pitches=gp))
+
+# config 2: 8 views of 256^2 (bench.py's poses for that workload)
+S = 256
+r.set_cam(r.cam_fov, S, S)
+torch.manual_seed(3)
+dump("cfg2", r.sample_cam_poses(8, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))

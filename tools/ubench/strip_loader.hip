@@ -1,0 +1,109 @@
+// Memory-path ceiling of the strip decomposition on gfx950: every wavefront owns a 32xROWS pixel strip and, plane after plane,
+// loads the texel box of the strip (bf16 planar volume [V][D][4][1024][1024], ~34 x (ROWS+1) texels per channel, 16 bytes per
+// lane and load at dword alignment) -- nothing else (the texels are folded into one register).  What is varied: planes of
+// loads in flight per wave (DEPTH), strips side by side per workgroup (WPB), waves per CU (LDS-limited occupancy), and whether
+// the four channel images are fetched by four loads (45 active lanes each) or by three full loads (FLAT).
+// Build: hipcc --offload-arch=gfx950 -O3 strip_loader.hip -o bin/strip_loader
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int W = 1024, H = 1024, D = 96, V = 4;
+
+__device__ __forceinline__ uint32_t fold(uint32_t m, u32x4 v) { return max(max(m, v.x), max(max(v.y, v.z), v.w)); }
+
+template <int DEPTH, int WPB, bool FLAT, int ROWS>
+__global__ __launch_bounds__(WPB * 64) void k(const uint16_t* __restrict__ vol, uint32_t* out, int n_tiles, int tiles_x, int tiles_y) {
+    extern __shared__ unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int per_xcd = (n_tiles + 7) / 8;
+    const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile_id >= n_tiles) return;
+    const int tpv = tiles_x * tiles_y;
+    const int n = tile_id / tpv, trem = tile_id - n * tpv;
+    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    const int sx0 = (txi * WPB + wv) * 32, sy0 = tyi * ROWS;
+    const uint16_t* base = vol + (size_t)n * D * 4 * H * W;
+    constexpr int NR = ROWS + 1;  // box rows
+    constexpr int NL = FLAT ? (4 * NR * 5 + 63) / 64 : 4 * ((NR * 5 + 63) / 64);
+    constexpr int PASSES = FLAT ? 1 : (NR * 5 + 63) / 64;
+    int ch[NL], lr[NL], lc[NL]; bool ok[NL];
+#pragma unroll
+    for (int q = 0; q < NL; ++q) {
+        if (FLAT) {
+            const int id = q * 64 + lane;
+            ok[q] = id < 4 * NR * 5;
+            ch[q] = id / (NR * 5); const int r = id - ch[q] * NR * 5;
+            lr[q] = r / 5; lc[q] = r - lr[q] * 5;
+        } else {
+            const int id = (q / 4) * 64 + lane;
+            ch[q] = q % 4; lr[q] = id / 5; lc[q] = id - lr[q] * 5; ok[q] = id < NR * 5;
+        }
+    }
+    (void)PASSES;
+    u32x4 L[DEPTH][NL];
+    auto issue = [&](int k, int slot) {
+        const float sc = 0.85f + 0.15f * k / D;
+        const int x0 = ((int)(sx0 * sc + 512.f * (1.f - sc))) & ~1, y0 = (int)(sy0 * sc + 512.f * (1.f - sc));
+        const uint16_t* pl = base + (size_t)k * 4 * H * W;
+#pragma unroll
+        for (int q = 0; q < NL; ++q) {
+            const int y = min(y0 + lr[q], H - 1), x = min(x0 + 8 * lc[q], W - 8);
+            const uint16_t* a = pl + (size_t)ch[q] * H * W + y * W + x;
+            u32x4 v = {0, 0, 0, 0};
+            if (ok[q]) v = *(const u32x4*)a;
+            L[slot][q] = v;
+        }
+    };
+    uint32_t m = 0;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(d, d);
+#pragma unroll 1
+    for (int k0 = 0; k0 < D; k0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int q = 0; q < NL; ++q) m = fold(m, L[d][q]);
+            issue(min(k0 + d + DEPTH, D - 1), d);
+        }
+    }
+    if (m == 0x12345678u) out[blockIdx.x] = m + smem[0];
+}
+
+template <int DEPTH, int WPB, bool FLAT, int ROWS>
+void run(const uint16_t* vol, uint32_t* out, int waves_per_cu) {
+    const int tiles_x = W / (WPB * 32), tiles_y = H / ROWS, n_tiles = tiles_x * tiles_y * V;
+    const int wgs = waves_per_cu / WPB;
+    if (wgs < 1) return;
+    const int lds = (160 * 1024 / wgs) & ~255;  // dynamic LDS caps the workgroups per CU
+    (void)hipFuncSetAttribute((const void*)k<DEPTH, WPB, FLAT, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9;
+    for (int it = 0; it < 4; ++it) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k<DEPTH, WPB, FLAT, ROWS>), dim3((n_tiles + 7) / 8 * 8), dim3(WPB * 64), lds, 0, vol, out, n_tiles, tiles_x, tiles_y);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (it) best = ms < best ? ms : best;
+    }
+    const double gb = (double)V * D * 4 * H * W * 2 / 1e9;
+    printf("depth=%d strips/wg=%d flat=%d rows=%2d waves/CU=%2d : %.3f ms  (%.2f TB/s of the volume)  %s\n", DEPTH, WPB, (int)FLAT, ROWS, waves_per_cu, best, gb / best,
+           hipGetErrorString(hipGetLastError()));
+    fflush(stdout);
+}
+
+int main() {
+    uint16_t* vol; uint32_t* out;
+    const size_t bytes = (size_t)V * D * 4 * H * W * 2;
+    (void)hipMalloc(&vol, bytes + 4096); (void)hipMalloc(&out, 1 << 20);
+    (void)hipMemset(vol, 0x11, bytes + 4096);
+    for (int wpc : {8, 12, 16, 24, 32}) {
+        run<1, 4, false, 8>(vol, out, wpc); run<2, 4, false, 8>(vol, out, wpc); run<3, 4, false, 8>(vol, out, wpc);
+        run<1, 4, true, 8>(vol, out, wpc); run<2, 4, true, 8>(vol, out, wpc);
+        run<1, 8, false, 8>(vol, out, wpc); run<2, 8, false, 8>(vol, out, wpc);
+    }
+    run<1, 4, false, 16>(vol, out, 12); run<2, 4, false, 16>(vol, out, 12); run<2, 4, false, 16>(vol, out, 16);
+    return 0;
+}
