@@ -146,3 +146,51 @@ def test_fuzz_strict_mode_is_bit_exact_on_random_small_problems():
             fast = hip_render(vol, dhw, ray, eye, zd, ac=cfg["ac"], variant=variant, check_last=False)
             assert np.abs(fast["color"] - orc["color"]).max() <= 0.5 * TOL, (i, cfg, variant)
             assert np.abs(fast["depth"] - orc["depth"]).max() <= TOL, (i, cfg, variant)
+
+
+def test_fp16_texel_staging_of_the_strip_kernel():
+    """16-bit volumes in default mode are staged as fp16 RGBA texels (render_wave.hip, HALF): exact for 2^-17 <= |v| <= 65280.
+    (a) colours fp16 cannot represent (1e6, -3e5; alpha stays in [0,1], range check off as MPI.forward allows): the planes that
+    hold them leave the staged loop through the direct gather -- relative agreement with the oracle; (b) values below fp16's
+    normal range (down to bf16's smallest subnormals' neighbourhood): truncated by < 2^-24, far inside the 1e-5 bar;
+    (c) an fp16 volume is staged verbatim (denormals included)."""
+    rgba, dhw, ray, eye, zd = _random_case(seed=61, B=2, D=9, S=256)
+    # (a) three planes with unrepresentable colours, spread over the image (several strips and both strip-kernel regimes)
+    big = rgba.clone()
+    big[0, 2, 0, 40:44, 100:140] = 1.0e6
+    big[1, 5, 1, 200, 17] = -3.0e5
+    big[0, 7, 2, 3, 250] = 7.0e4
+    stored = big.to(torch.bfloat16)
+    orc = oracle.render(stored.float(), dhw, ray, eye, zd, threads=True)
+    for variant in ("wave", "lds"):
+        out = hip_render(stored, dhw, ray, eye, zd, variant=variant, range_check="off")
+        for k in ("color", "depth", "T"):
+            err = np.abs(out[k] - orc[k]) / np.maximum(1.0, np.abs(orc[k]))
+            assert err.max() <= 0.5 * TOL, (variant, k, float(err.max()))
+    # (b) tiny values in every channel of a band of texels
+    tiny = rgba.clone()
+    tiny[:, :, :, 64:96, :] *= 2.0 ** -18
+    tiny[:, :, :, 96:128, :] *= 2.0 ** -30
+    for dt in (torch.bfloat16, torch.float16):
+        stored = tiny.to(dt)
+        orc = oracle.render(stored.float(), dhw, ray, eye, zd, threads=True)
+        out = hip_render(stored, dhw, ray, eye, zd, variant="wave")
+        assert np.abs(out["color"] - orc["color"]).max() <= 0.5 * TOL and np.abs(out["depth"] - orc["depth"]).max() <= TOL, dt
+        assert np.abs(out["T"] - orc["T"]).max() <= TOL, dt
+    # (c) the fp16 path adds no error of its own: default mode with fp16 texels == default mode of the tile kernel (fp32 arithmetic
+    # on exactly the same values, same FMA order)
+    stored = rgba.to(torch.float16)
+    a, b = hip_render(stored, dhw, ray, eye, zd, variant="wave"), hip_render(stored, dhw, ray, eye, zd, variant="lds")
+    assert np.abs(a["color"] - b["color"]).max() <= 2e-7 and np.abs(a["depth"] - b["depth"]).max() <= 2e-6
+
+
+def test_strip_kernel_two_waves_per_simd_regime():
+    """Launches of 1025..2048 strips (BASELINE config 2: 8 x 256^2) run the 2-waves-per-SIMD instance of the strip kernel
+    (20 KB of LDS per wave): all storage types against the oracle, default mode; strict mode stays bit-exact."""
+    rgba, dhw, ray, eye, zd = _random_case(seed=71, B=6, D=11, S=256)  # 1536 strips
+    _check(rgba, dhw, ray, eye, zd, variants=("wave",))
+    for dt in (torch.bfloat16, torch.float16):
+        stored = rgba.to(dt)
+        orc = oracle.render(stored.float(), dhw, ray, eye, zd, threads=True)
+        fast = hip_render(stored, dhw, ray, eye, zd, variant="wave")
+        assert np.abs(fast["color"] - orc["color"]).max() <= 0.5 * TOL and np.abs(fast["depth"] - orc["depth"]).max() <= TOL, dt
