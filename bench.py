@@ -7,7 +7,8 @@
 
 Metric (BASELINE.json): Mpix*planes/s = views*H*W*D / t / 1e6 (whole job, all GPUs), plus views/s and
 the fraction of the HBM roofline.  A "step" = ONE pass of the hot path over one batch of views
-(one fused kernel launch: warp + composite + depth + asserts), inputs resident in HBM.
+(one fused kernel launch: warp + composite + depth + asserts), inputs resident in HBM.  Before the W warm-up steps the
+same launch is repeated for --prewarm-ms (default 250 ms, untimed) so that a GPU coming from idle has reached its busy clocks.
 
 Default workload = BASELINE.json configs[2] ("FFHQ1024-shaped: 1024x1024, 96 planes, batch 4 views,
 bf16", the configuration the north-star target is quoted on); each rank renders its own batch
@@ -133,6 +134,9 @@ def main():
     ap.add_argument("--strict", action="store_true", help="strict-order arithmetic (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--prewarm-ms", type=float, default=250.0,
+                    help="untimed render launches for this long before the W warm-up steps: a GPU coming from idle needs ~0.1 s to reach "
+                         "its busy clocks (20 steps are only 23 ms of work); 0 disables")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -192,6 +196,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     with torch.no_grad():
+        if a.prewarm_ms > 0:  # clock ramp (untimed, before the W warm-up steps)
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < a.prewarm_ms:
+                for _ in range(8):
+                    step()
+                torch.cuda.synchronize(dev)
         for _ in range(a.warmup):
             step()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]

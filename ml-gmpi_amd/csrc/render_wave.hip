@@ -353,9 +353,8 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
         // ---- compositing of one plane, taps from the wave's LDS box.  Two pixels at a time: both coordinate chains, then all 8
         //      tap reads, then the arithmetic -- half as many waits for LDS data as one pixel at a time, at 32 registers of taps
         //      (all four pixels at once, 64 registers of taps, measured slower: 1.32 vs 1.19 ms) ----
-        auto composite = [&](int k, auto full_tag) __attribute__((always_inline)) {
+        auto composite = [&](const u32x4_t& lo, const u32x4_t& hi, auto full_tag) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;  // all four pixels of a lane (compile time: no per-pixel branches)
-            const u32x4_t lo = tab[2 * (k & (kRing - 1))], hi = tab[2 * (k & (kRing - 1)) + 1];
             const float zdiff = __uint_as_float(lo.w), hw = __uint_as_float(hi.x), hh = __uint_as_float(hi.y);
             const float rw = __uint_as_float(hi.z), rh = __uint_as_float(hi.w);
             const uint32_t row_bytes = static_cast<uint32_t>(SS) * static_cast<uint32_t>(pitch);
@@ -479,8 +478,7 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                 // was measured twice this round, with fp32 and with fp16 texels: no gain, profiles/r02_variants.txt)
                 using LoadRegs = u32x4_t[NPC][4];
                 LoadRegs La;
-                auto issue = [&](int k, LoadRegs& L) __attribute__((always_inline)) {
-                    const u32x4_t lo = tab[2 * (k & (kRing - 1))];
+                auto issue = [&](const u32x4_t& lo, int k, LoadRegs& L) __attribute__((always_inline)) {
                     const uint32_t clo = lo.y & 0xffu, ncol = (lo.y >> 8) & 0xffu, nrk = lo.y >> 24;
                     const bool xok = lane_ok & (static_cast<uint32_t>(lc) - clo < ncol);
 #ifdef GMPI_TUNE
@@ -539,9 +537,9 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                     }
                     }
                 };
-                auto stage = [&](int k, LoadRegs& L) __attribute__((always_inline)) {
+                auto stage = [&](const u32x4_t& lo_k, LoadRegs& L) __attribute__((always_inline)) {
                     uint32_t mx = 0;
-                    const uint32_t phase = __builtin_amdgcn_readfirstlane((tab[2 * (k & (kRing - 1))].y >> 16) & 7u);
+                    const uint32_t phase = __builtin_amdgcn_readfirstlane((lo_k.y >> 16) & 7u);
                     uint32_t dstk = dst0;
                     bool dup = true;
                     if constexpr (TPI == 4) {  // (phase is 0 or 4: whether even or odd items start an 8-column block)
@@ -589,24 +587,34 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
                     }
                     return HALF && __any(unsafe);
                 };
+                // The ring entry of a plane (two 16-byte LDS broadcasts) is read one plane ahead: by the time the loader and the
+                // compositor need it, the data has long arrived -- the plane loop has no wait for per-plane uniforms.
+                auto entry = [&](int k, u32x4_t& lo, u32x4_t& hi) __attribute__((always_inline)) {
+                    lo = tab[2 * (k & (kRing - 1))], hi = tab[2 * (k & (kRing - 1)) + 1];
+                };
                 fill(k_begin);
-                issue(k_begin, La);
+                u32x4_t lo, hi, lon, hin;
+                entry(k_begin, lo, hi);
+                issue(lo, k_begin, La);
 #pragma unroll 1
                 for (int g0 = k_begin; g0 < k_end; g0 += kGroup) {
                     if (g0 + kGroup < k_end) fill(g0 + kGroup);  // the slots of planes [g0 - 16, g0) are consumed
                     const int g1 = min(g0 + kGroup, k_end);
 #pragma unroll 1
                     for (int k = g0; k < g1; ++k) {
-                        const bool by_gather = stage(k, La);  // box of plane k -> LDS (after this wave's reads of plane k-1: LDS is in order)
-                        issue(min(k + 1, k_end - 1), La);  // in flight while plane k is composited
+                        const int kn = min(k + 1, k_end - 1);
+                        entry(kn, lon, hin);
+                        const bool by_gather = stage(lo, La);  // box of plane k -> LDS (after this wave's reads of plane k-1: LDS is in order)
+                        issue(lon, kn, La);  // in flight while plane k is composited
 #ifdef GMPI_TUNE
-                        if (p.flags & (1u << 25)) continue;  // ablation: loader only
+                        if (p.flags & (1u << 25)) { lo = lon, hi = hin; continue; }  // ablation: loader only
 #endif
                         // HALF: a plane holding a value fp16 cannot represent ends the staged loop; the caller composites the
                         // rest of the planes by the direct gather (a side exit instead of a second path through the loop body:
                         // no copies of the accumulators where two paths would merge)
                         if (HALF && __builtin_expect(by_gather, 0)) return k;
-                        composite(k, full_tag);
+                        composite(lo, hi, full_tag);
+                        lo = lon, hi = hin;
                     }
                 }
                 return k_end;
