@@ -61,7 +61,7 @@ enum {
     GMPI_VARIANT_AUTO = 0,
     GMPI_VARIANT_GATHER = 1, /* one pixel per lane, taps straight from global memory (any shape/stride) */
     GMPI_VARIANT_LDS = 2,    /* pixel tiles, texel boxes staged through LDS with 16-byte row loads      */
-    GMPI_VARIANT_WAVE = 3    /* wave-private 32x8 pixel strips, fp32 RGBA boxes in LDS (the default)    */
+    GMPI_VARIANT_WAVE = 3    /* wave-private 32x8 pixel strips, whole RGBA texels (fp32 / fp16) in LDS  */
 };
 
 enum {

@@ -259,14 +259,19 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     int variant = params->variant;
     if (variant == GMPI_VARIANT_AUTO) {
-        // Measured on MI355X (profiles/r02_variants.txt): the tile kernel wins on large launches (configs 3-5: 32 waves per CU
-        // hide its latencies, its shared 32x16 boxes tolerate tilted cameras); the strip kernel wins when the launch under-fills
-        // the chip (config 2, 8 views of 256^2: 4 pixels per lane need a quarter of the waves; single small views: its waves
-        // split the planes).  Strict-order mode has no plane split: there only launches of 2^18 .. 2^19 pixels go to it.
+        // Measured on MI355X at steady clocks (profiles/r02_variants.txt, "small launches"): the tile kernel wins on large
+        // launches (configs 3-5: 32 waves per CU hide its latencies, its shared 32x16 boxes tolerate tilted cameras); the strip
+        // kernel wins where the launch under-fills the chip: up to 512 strips of 32x8 pixels (its waves split the planes 6-way),
+        // 16-bit volumes up to 1024 strips (3-way), and fp32 volumes between 1537 and 2048 strips (config 2, 8 views of 256^2:
+        // the tile kernel needs a second round of workgroups there, 3 x 53 KB of LDS per CU).  Strict-order mode has no plane
+        // split: there only launches of 2^18 .. 2^19 pixels go to the strip kernel.
         const int64_t pixels = static_cast<int64_t>(p.N) * p.H * p.W;
+        const int64_t strips = static_cast<int64_t>(p.N) * ((p.W + 31) / 32) * ((p.H + 7) / 8);
         const bool strict = (p.flags & GMPI_FLAG_STRICT_ORDER) != 0;
         const bool lds_ok = lds_variant_supports(p, params->rgba_dtype), wave_ok = wave_variant_supports(p, params->rgba_dtype);
-        const bool small = pixels <= (int64_t(1) << 19) && (!strict || pixels > (int64_t(1) << 18));
+        const bool small = strict ? (pixels <= (int64_t(1) << 19) && pixels > (int64_t(1) << 18))
+                         : params->rgba_dtype == GMPI_DTYPE_F32 ? (strips <= 512 || (strips > 1536 && strips <= 2048))
+                                                                : strips <= 1024;
         variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
     }
     if (variant == GMPI_VARIANT_GATHER) {

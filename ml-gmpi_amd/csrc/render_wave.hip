@@ -9,18 +9,27 @@
 //   * a wavefront owns a 32x8 pixel STRIP (4 pixels per lane: rows y, y+2, y+4, y+6) and stages the texel box of the strip
 //     privately: its own LDS region, its own prefetch registers, no workgroup barrier on the data path (LDS operations of
 //     one wave execute in order, so the box of plane k+1 may overwrite plane k's without any wait); 4 strips side by side per
-//     workgroup, 12 waves per CU (168 VGPRs, 13 KB of LDS each);
-//   * texels are stored in LDS as fp32 RGBA (16 bytes per texel): the storage->fp32 conversion is paid once per staged texel
-//     (~1.1-1.3 per pixel) by the loader instead of 16x per pixel by the compositor, a pixel's 16 taps are four
-//     ds_read_b128, and there is no unpack code in the compositor at all: 54 vector instructions per pixel and plane (the
-//     exact coordinate chain 17, v_fract / v_cvt_flr 4, weights 6, tap address 5, bilinear 16, blend 9, minus shared ones);
+//     workgroup, 12 waves per CU (168 VGPRs, 13 KB of LDS each); launches of 1025-2048 strips run an 8-waves-per-CU build
+//     (up to 256 VGPRs, no scratch), smaller ones split the planes of a strip over 3 or 6 waves (SPLIT, below);
+//   * texels are stored in LDS as whole RGBA texels, converted once per staged texel (~1.5 per pixel) by the loader instead of
+//     16x per pixel by the compositor: 54 vector instructions per pixel and plane (the exact coordinate chain 17, v_fract /
+//     v_cvt_flr 4, weights 6, tap address 5, bilinear 16, blend 9, minus shared ones).  Two texel formats:
+//       - fp32 RGBA, 16 bytes (fp32 volumes; the strict-order mode): a pixel's taps are four ds_read_b128;
+//       - fp16 RGBA, 8 bytes (HALF: bf16 / fp16 volumes in default mode): half the LDS bytes and tap registers, boxes twice
+//         as large fit (tilted cameras need no half-strip pass up to ~0.5 rad of yaw), and the fp32 conversion happens inside
+//         the bilinear FMAs (v_fma_mix_f32).  bf16 -> fp16 is exact for 2^-17 <= |v| <= 65280 (smaller values are truncated
+//         by < 2^-24, far below the 1e-5 bar; a plane holding a larger value, inf or NaN is detected by the range-check
+//         maximum the loader keeps anyway and leaves the staged loop through the direct gather: correct for any input).
+//         Measured (profiles/r02_variants.txt): LDS busy -17 %, waits for LDS data -80 %, bench poses 1.037 vs 1.034 ms for
+//         the tile kernel, 1.18 vs 1.07 ms at tilted poses;
 //   * 16-byte loads (8 half-precision / 4 fp32 texels of each of the four channel images per lane) at dword alignment:
 //     4 load instructions per wave and plane, boxes as tight as the footprint (32 texels per row);
-//   * LDS rows are padded by one slot per 8 texture columns (holding a copy of the next texel), which makes the 16-byte
-//     stores of a wave conflict-free (lanes 9 slots apart) while the compositor still reads slot and slot + 1;
+//   * LDS rows are padded by one (fp32 texels) or two (fp16 texels) slots per 8 texture columns -- the first holds a copy of
+//     the next texel -- which makes the 16-byte stores of a wave conflict-free (lanes 144 / 80 bytes apart: 8 consecutive
+//     lanes hit 8 different 16-byte bank groups) while the compositor still reads slot and slot + 1;
 //   * everything that is uniform per plane (box origin, texture bounds, LDS address constant, plane constants and their
 //     correctly rounded reciprocals) is computed by one lane per plane and corner, 16 planes per round, into a 32-entry ring
-//     in the wave's LDS region and read back as two 16-byte broadcasts per plane;
+//     in the wave's LDS region and read back as two 16-byte broadcasts per plane, one plane ahead of their use;
 //   * texture bounds along y are left to the buffer range check (one descriptor per channel image -- on gfx950 the scalar
 //     offset of a buffer load takes part in the range check, so it cannot carry the channel): rows above/below the image
 //     read as the zeros F.grid_sample's padding wants; only the x test is explicit, once per plane.
@@ -157,7 +166,6 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
     static_assert(SPLIT == 1 || !STRICT, "plane split changes the association of the composite");
     static_assert(!HALF || (!STRICT && sizeof(TexT) == 2), "fp16 texels in LDS: 16-bit volumes, default mode");
     __shared__ __attribute__((aligned(16))) unsigned char smem[WPB * SPLIT * kWaveLds];
-
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);
 
@@ -474,8 +482,10 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
 
             auto run = [&](auto np, auto full_tag) -> int {
                 constexpr int NPC = decltype(np)::value;
-                // the loads of the next plane, in flight while the current one is composited (a second plane of loads in flight
-                // was measured twice this round, with fp32 and with fp16 texels: no gain, profiles/r02_variants.txt)
+                // the loads of the next plane, in flight while the current one is composited.  (A second plane of loads in flight
+                // gained < 1 % -- hipcc's waitcnt insertion waits for ALL outstanding loads on every other plane of the two-plane
+                // loop, and the loads-only microbenchmark gets slower, not faster, with 8 instead of 4 buffer loads per wave in
+                // flight: profiles/r02_variants.txt, tools/ubench/strip_loader.hip.)
                 using LoadRegs = u32x4_t[NPC][4];
                 LoadRegs La;
                 auto issue = [&](const u32x4_t& lo, int k, LoadRegs& L) __attribute__((always_inline)) {

@@ -1,5 +1,5 @@
 // kbench -- torch-free timing / cross-check harness for the render kernels, through the C ABI (include/gmpi_render.h).
-//   kbench <lib.so> <set: gpurun_in/kb_<set>.bin> <bf16|f16|f32> <variant[:s][,variant...]> [reps]
+//   kbench <lib.so> <set: gpurun_in/kb_<set>.bin> <bf16|f16|f32> <variant[:s][,variant...]> [reps] [views]
 // variant = auto | gather | lds | wave ; ":s" = strict-order mode.  The first variant is the reference of the cross-check
 // (max |difference| of colour and depth against it).  Camera tensors come from tools/kbench_dump.py (bench.py's poses).
 // Build: hipcc --offload-arch=gfx950 -O2 -I include tools/kbench.cpp -o tools/ubench/bin/kbench -ldl
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
     if (!f) { printf("no input set %s\n", set.c_str()); return 1; }
     int hdr[3];
     if (fread(hdr, 4, 3, f) != 3) return 1;
-    const int N = hdr[0], S = hdr[1], D = hdr[2];
+    const int N = (argc > 6 && atoi(argv[6]) > 0 && atoi(argv[6]) < hdr[0]) ? atoi(argv[6]) : hdr[0], S = hdr[1], D = hdr[2];  // [views]: the first n of the set
     float focal;
     std::vector<float> dhw1(D * 3), c2w(N * 16), eye(N * 3), zd(N * 3), ray((size_t)N * 3 * S * S);
     if (fread(&focal, 4, 1, f) != 1 || fread(dhw1.data(), 4, dhw1.size(), f) != dhw1.size() || fread(c2w.data(), 4, c2w.size(), f) != c2w.size()) { printf("short file\n"); return 1; }
@@ -93,7 +93,14 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(rgb.data(), d_rgb, npix * 12, hipMemcpyDeviceToHost)); CK(hipMemcpy(dep.data(), d_dep, npix * 4, hipMemcpyDeviceToHost));
         uint32_t st[4]; CK(hipMemcpy(st, d_st, 16, hipMemcpyDeviceToHost));
         float best = 1e9, sum = 0;
-        for (int i = 0; i < 3; ++i) launch(&p, nullptr);  // warm-up (clock ramp)
+        {  // warm-up: ~0.25 s of launches (a GPU coming from idle needs ~0.1 s to reach its busy clocks)
+            hipEvent_t w0, w1; CK(hipEventCreate(&w0)); CK(hipEventCreate(&w1));
+            float acc = 0;
+            while (acc < 250.f) {
+                CK(hipEventRecord(w0)); for (int i = 0; i < 16; ++i) launch(&p, nullptr); CK(hipEventRecord(w1)); CK(hipEventSynchronize(w1));
+                float ms; CK(hipEventElapsedTime(&ms, w0, w1)); acc += ms;
+            }
+        }
         for (int i = 0; i < reps; ++i) {
             CK(hipEventRecord(e0)); launch(&p, nullptr); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best; sum += ms;

@@ -40,3 +40,8 @@ S = 256
 r.set_cam(r.cam_fov, S, S)
 torch.manual_seed(3)
 dump("cfg2", r.sample_cam_poses(8, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))
+
+S = 512
+r.set_cam(r.cam_fov, S, S)
+torch.manual_seed(3)
+dump("s512", r.sample_cam_poses(8, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))

@@ -14,7 +14,7 @@ constexpr int W = 1024, H = 1024, D = 96, V = 4;
 
 __device__ __forceinline__ uint32_t fold(uint32_t m, u32x4 v) { return max(max(m, v.x), max(max(v.y, v.z), v.w)); }
 
-template <int DEPTH, int WPB, bool FLAT, int ROWS>
+template <int DEPTH, int WPB, bool FLAT, int ROWS, int SLEEP = 0>
 __global__ __launch_bounds__(WPB * 64) void k(const uint16_t* __restrict__ vol, uint32_t* out, int n_tiles, int tiles_x, int tiles_y) {
     extern __shared__ unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -53,7 +53,13 @@ __global__ __launch_bounds__(WPB * 64) void k(const uint16_t* __restrict__ vol, 
             const int y = min(y0 + lr[q], H - 1), x = min(x0 + 8 * lc[q], W - 8);
             const uint16_t* a = pl + (size_t)ch[q] * H * W + y * W + x;
             u32x4 v = {0, 0, 0, 0};
-            if (ok[q]) v = *(const u32x4*)a;
+            if (SLEEP >= 100 && SLEEP < 200) {  // the render kernels' way: one buffer descriptor per channel image, lanes outside the box get an
+                                 // offset beyond num_records (hardware returns zeros, no exec-mask change)
+                const uint16_t* cb = pl + (size_t)ch[q] * H * W;
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(cb), 0, H * W * 2, 0x00020000);
+                const uint32_t off = ok[q] ? (uint32_t)((y * W + x) * 2) : 0x80000000u;
+                v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            } else if (ok[q]) v = *(const u32x4*)a;
             L[slot][q] = v;
         }
     };
@@ -66,39 +72,57 @@ __global__ __launch_bounds__(WPB * 64) void k(const uint16_t* __restrict__ vol, 
         for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
             for (int q = 0; q < NL; ++q) m = fold(m, L[d][q]);
+            // SLEEP: the wave does something else for SLEEP x 64 cycles between the arrival of a plane and the issue of the next
+            // loads (the real loaders: range-check maximum, table read from LDS, ~60 scalar instructions for the descriptors)
+            if (SLEEP >= 200) __syncthreads();
+            if (SLEEP % 100 > 0) asm volatile("s_sleep %1" : "+v"(m) : "n"(SLEEP % 100));  // (after the fold: "+v"(m) orders it)
             issue(min(k0 + d + DEPTH, D - 1), d);
         }
     }
     if (m == 0x12345678u) out[blockIdx.x] = m + smem[0];
 }
 
-template <int DEPTH, int WPB, bool FLAT, int ROWS>
+template <int DEPTH, int WPB, bool FLAT, int ROWS, int SLEEP = 0>
 void run(const uint16_t* vol, uint32_t* out, int waves_per_cu) {
     const int tiles_x = W / (WPB * 32), tiles_y = H / ROWS, n_tiles = tiles_x * tiles_y * V;
     const int wgs = waves_per_cu / WPB;
     if (wgs < 1) return;
     const int lds = (160 * 1024 / wgs) & ~255;  // dynamic LDS caps the workgroups per CU
-    (void)hipFuncSetAttribute((const void*)k<DEPTH, WPB, FLAT, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)k<DEPTH, WPB, FLAT, ROWS, SLEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e9;
     for (int it = 0; it < 4; ++it) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((k<DEPTH, WPB, FLAT, ROWS>), dim3((n_tiles + 7) / 8 * 8), dim3(WPB * 64), lds, 0, vol, out, n_tiles, tiles_x, tiles_y);
+        hipLaunchKernelGGL((k<DEPTH, WPB, FLAT, ROWS, SLEEP>), dim3((n_tiles + 7) / 8 * 8), dim3(WPB * 64), lds, 0, vol, out, n_tiles, tiles_x, tiles_y);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (it) best = ms < best ? ms : best;
     }
     const double gb = (double)V * D * 4 * H * W * 2 / 1e9;
-    printf("depth=%d strips/wg=%d flat=%d rows=%2d waves/CU=%2d : %.3f ms  (%.2f TB/s of the volume)  %s\n", DEPTH, WPB, (int)FLAT, ROWS, waves_per_cu, best, gb / best,
+    printf("sleep=%2d depth=%d strips/wg=%d flat=%d rows=%2d waves/CU=%2d : %.3f ms  (%.2f TB/s of the volume)  %s\n", SLEEP, DEPTH, WPB, (int)FLAT, ROWS, waves_per_cu, best, gb / best,
            hipGetErrorString(hipGetLastError()));
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
     uint16_t* vol; uint32_t* out;
     const size_t bytes = (size_t)V * D * 4 * H * W * 2;
     (void)hipMalloc(&vol, bytes + 4096); (void)hipMalloc(&out, 1 << 20);
     (void)hipMemset(vol, 0x11, bytes + 4096);
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL((k<1, 4, false, 8, 0>), dim3(16384 / 4), dim3(256), 0, 0, vol, out, 4096, 8, 128);  // clock ramp
+    (void)hipDeviceSynchronize();
+    if (argc > 1) {  // the gap between the arrival of a plane and the next loads, at 12 waves per CU
+        run<1, 4, false, 8, 0>(vol, out, 12); run<1, 4, false, 8, 2>(vol, out, 12); run<1, 4, false, 8, 4>(vol, out, 12); run<1, 4, false, 8, 8>(vol, out, 12);
+        run<1, 4, false, 8, 16>(vol, out, 12);
+        run<2, 4, false, 8, 4>(vol, out, 12); run<2, 4, false, 8, 8>(vol, out, 12); run<2, 4, false, 8, 16>(vol, out, 12);
+        run<3, 4, false, 8, 8>(vol, out, 12); run<3, 4, false, 8, 16>(vol, out, 12);
+        // buffer loads through per-channel descriptors, lanes outside the box out of range (sleep >= 100)
+        run<1, 4, false, 8, 100>(vol, out, 12); run<2, 4, false, 8, 100>(vol, out, 12); run<1, 4, false, 8, 108>(vol, out, 12); run<2, 4, false, 8, 108>(vol, out, 12);
+        run<1, 4, false, 8, 100>(vol, out, 8); run<1, 4, false, 8, 100>(vol, out, 16);
+        // a workgroup barrier per plane (sleep >= 200): do drifting waves cost DRAM / L2 locality?
+        for (int wpc : {12, 16, 24, 32}) { run<1, 4, false, 8, 0>(vol, out, wpc); run<1, 4, false, 8, 200>(vol, out, wpc); run<1, 8, false, 8, 200>(vol, out, wpc); }
+        return 0;
+    }
     for (int wpc : {8, 12, 16, 24, 32}) {
         run<1, 4, false, 8>(vol, out, wpc); run<2, 4, false, 8>(vol, out, wpc); run<3, 4, false, 8>(vol, out, wpc);
         run<1, 4, true, 8>(vol, out, wpc); run<2, 4, true, 8>(vol, out, wpc);
