@@ -1,5 +1,5 @@
 // kbench -- torch-free timing / cross-check harness for the render kernels, through the C ABI (include/gmpi_render.h).
-//   kbench <lib.so> <set: gpurun_in/kb_<set>.bin> <bf16|f16|f32> <variant[:s][,variant...]> [reps] [views]
+//   kbench <lib.so> <set: gpurun_in/kb_<set>.bin> <bf16|f16|f32> <variant[:s][,variant...]> [reps] [views] [planes]
 // variant = auto | gather | lds | wave ; ":s" = strict-order mode.  The first variant is the reference of the cross-check
 // (max |difference| of colour and depth against it).  Camera tensors come from tools/kbench_dump.py (bench.py's poses).
 // Build: hipcc --offload-arch=gfx950 -O2 -I include tools/kbench.cpp -o tools/ubench/bin/kbench -ldl
@@ -44,9 +44,10 @@ int main(int argc, char** argv) {
     if (!f) { printf("no input set %s\n", set.c_str()); return 1; }
     int hdr[3];
     if (fread(hdr, 4, 3, f) != 3) return 1;
-    const int N = (argc > 6 && atoi(argv[6]) > 0 && atoi(argv[6]) < hdr[0]) ? atoi(argv[6]) : hdr[0], S = hdr[1], D = hdr[2];  // [views]: the first n of the set
+    const int N = (argc > 6 && atoi(argv[6]) > 0 && atoi(argv[6]) < hdr[0]) ? atoi(argv[6]) : hdr[0], S = hdr[1], Dfile = hdr[2];  // [views]: the first n of the set
+    const int D = (argc > 7 && atoi(argv[7]) > 0 && atoi(argv[7]) < Dfile) ? atoi(argv[7]) : Dfile;  // [planes]: the nearest d of the set
     float focal;
-    std::vector<float> dhw1(D * 3), c2w(N * 16), eye(N * 3), zd(N * 3), ray((size_t)N * 3 * S * S);
+    std::vector<float> dhw1(Dfile * 3), c2w(hdr[0] * 16), eye(N * 3), zd(N * 3), ray((size_t)N * 3 * S * S);
     if (fread(&focal, 4, 1, f) != 1 || fread(dhw1.data(), 4, dhw1.size(), f) != dhw1.size() || fread(c2w.data(), 4, c2w.size(), f) != c2w.size()) { printf("short file\n"); return 1; }
     fclose(f);
     for (int n = 0; n < N; ++n) {  // camera.py:98-118, 182-211: K^-1 [x + .5, y + .5, 1] normalised (float64), cast, rotated

@@ -24,7 +24,7 @@ def dump(name, cam):
     c2w, eye = cam[2].float().numpy(), torch.cat(cam[4]).float().numpy()
     dhw = r.static_mpi_plane_dhws.reshape(-1, 3).float().numpy()
     with open(os.path.join(ROOT, "gpurun_in", f"kb_{name}.bin"), "wb") as f:
-        np.array([c2w.shape[0], r.cam.height, D], dtype=np.int32).tofile(f)
+        np.array([c2w.shape[0], r.cam.height, r.static_mpi_plane_dhws.reshape(-1, 3).shape[0]], dtype=np.int32).tofile(f)
         np.array([r.cam.intrinsic_matrix[0, 0]], dtype=np.float32).tofile(f)
         dhw.astype(np.float32).tofile(f); c2w.astype(np.float32).tofile(f)
     print(name, c2w.shape, eye.tolist())
@@ -45,3 +45,13 @@ S = 512
 r.set_cam(r.cam_fov, S, S)
 torch.manual_seed(3)
 dump("s512", r.sample_cam_poses(8, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))
+
+# config 5: MetFaces preset, 256 planes, 1024^2
+kw = dict(PRESETS["MetFaces"])
+kw.update(n_mpi_planes=256, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse", cam_sample_method="truncated_gaussian",
+          mpi_align_corners=True, use_confined_volume=True, device=torch.device("cpu"))
+r = MPIRenderer(**kw)
+S, D = 1024, 256
+r.set_cam(r.cam_fov, S, S)
+torch.manual_seed(3)
+dump("c5", r.sample_cam_poses(4, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))
