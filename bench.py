@@ -12,7 +12,8 @@ same launch is repeated for --prewarm-ms (default 250 ms, untimed) so that a GPU
 
 Default workload = BASELINE.json configs[2] ("FFHQ1024-shaped: 1024x1024, 96 planes, batch 4 views,
 bf16", the configuration the north-star target is quoted on); each rank renders its own batch
-(independent views/seeds, no data-path collective -> "weak" scaling).  The final frame all_gather
+(independent views/seeds -- own volumes per rank, the same pose draw on every rank so that the per-GPU work is exactly
+fixed -- no data-path collective -> "weak" scaling).  The final frame all_gather
 (RCCL) is timed separately (`gather_ms`), outside the K timed steps.
 
 roofline.achieved = ALGORITHMIC bytes per launch / average kernel duration (HIP events around every
@@ -169,7 +170,10 @@ def main():
     for i in range(n_mpis):  # per-MPI fill keeps the transient fp32 copy small
         rgba[i] = torch.rand((D, 4, S, S), device=dev, generator=g).to(rgba.dtype)
     rgba[:, -1, 3] = 1.0  # background_alpha_full (networks_cond_on_pos_enc.py:1307-1310)
-    torch.manual_seed(3 + rank)
+    # camera poses: the same draw from the dataset's pose distribution on every rank (seed 3) -- the volumes differ per rank, the
+    # per-GPU work does not (kernel time depends on camera tilt by a few per cent: with per-rank pose seeds the max-over-ranks
+    # time of a weak-scaling run would measure pose luck, not scaling)
+    torch.manual_seed(3)
     if a.workload == "cfg4":  # video path: yaw sweep, pitch 0 (render_video.py:236-237), this rank's 8 of 64 views
         import numpy as np
         yaw = np.linspace(0.5, -0.5, 8 * world)[rank::world]
@@ -297,7 +301,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "name": a.workload, "views_per_gpu": n_views, "H": S, "W": S, "planes": D,
                        "rgba_storage": dtype, "variant": a.variant, "strict_order": a.strict,
-                       "outputs": "rgb+depth" + ("+transmittance" if want_T else ""), "parallelism": f"views sharded x{world}"},
+                       "outputs": "rgb+depth" + ("+transmittance" if want_T else ""), "parallelism": f"views sharded x{world}",
+                       "poses": "cfg4: yaw sweep 0.5..-0.5 split over the ranks" if a.workload == "cfg4" else "truncated-gaussian draw (seed 3) on every rank"},
             "views_per_s": round(n_views * world * a.steps / elapsed, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
