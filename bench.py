@@ -279,9 +279,10 @@ def main():
                     traffic = ent.get("hbm_bytes_per_launch")
                     traffic_note = ent.get("source", "profiles/hbm_traffic.json")
                     if ent.get("valu_insts_per_launch"):
-                        # wave64 VALU instructions / 1024 SIMDs x the issue cost measured by tools/ubench/clock_probe.hip with
-                        # every CU busy (fp32 1.24 ns, integer 1.73 ns per instruction and SIMD; the kernel's mix ~1.45 ns)
-                        valu_floor_ms = round(ent["valu_insts_per_launch"] / 1024 * 1.45e-6, 4)
+                        # wave64 VALU instructions / 1024 SIMDs x the issue cost measured with every CU busy at steady clocks
+                        # (tools/ubench/mix_rate.hip, profiles/r02b_mix_rate_steady.txt: fp32 1.08 ns, integer 1.64 ns, fp16 mix /
+                        # conversions 1.76 ns per instruction and SIMD; the tile kernel's 60 / 40 fp32 / integer mix: 1.30 ns)
+                        valu_floor_ms = round(ent["valu_insts_per_launch"] / 1024 * 1.30e-6, 4)
             except Exception as e:
                 traffic_note = f"unreadable: {e}"
         # streaming-read ceiling of THIS box, measured in-run: one pass of the exhaustive range check over the same volume

@@ -43,6 +43,10 @@ __global__ void k(float* out, int iters) {
             REP16(asm volatile("v_fma_mix_f32 %0, %8, %9, %0\n v_fma_mix_f32 %1, %8, %9, %1\n v_fma_mix_f32 %2, %8, %9, %2\n v_fma_mix_f32 %3, %8, %9, %3\n"
                                "v_fma_mix_f32 %4, %8, %9, %4\n v_fma_mix_f32 %5, %8, %9, %5\n v_fma_mix_f32 %6, %8, %9, %6\n v_fma_mix_f32 %7, %8, %9, %7\n"
                                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
+        } else if (MODE == 8) {  // the integer class of the render kernels: shifts, and, add, perm
+            REP16(asm volatile("v_lshlrev_b32 %0, 16, %1\n v_and_b32 %1, 0xffff0000, %2\n v_add_u32 %2, %3, %8\n v_perm_b32 %3, %4, %5, %8\n"
+                               "v_lshlrev_b32 %4, 16, %5\n v_and_b32 %5, 0xffff0000, %6\n v_add_u32 %6, %7, %8\n v_perm_b32 %7, %0, %1, %8\n"
+                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
         } else if (MODE == 7) {  // the compositor's mix: 2 fma_f32 : 1 mul : 1 add (reference rate for a blend of classes)
             REP16(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_mul_f32 %1, %1, %8\n v_fma_f32 %2, %2, %8, %9\n v_add_f32 %3, %3, %9\n"
                                "v_fma_f32 %4, %4, %8, %9\n v_mul_f32 %5, %5, %8\n v_fma_f32 %6, %6, %8, %9\n v_add_f32 %7, %7, %9\n"
@@ -70,10 +74,15 @@ void run(const char* name, int waves_per_simd) {
 }
 
 int main() {
+    {  // clock ramp: ~0.3 s of VALU work before anything is timed (a GPU coming from idle runs its first ~30 ms at low clocks)
+        float* out; hipMalloc(&out, 256 * 1024 * sizeof(float));
+        for (int i = 0; i < 60; ++i) k<0><<<256, 1024>>>(out, 2000);
+        hipDeviceSynchronize(); hipFree(out);
+    }
     for (int w : {2, 4}) {
         run<0>("v_fma_f32", w); run<1>("v_fma_mix_f32 (f16 lo/hi src1)", w); run<6>("v_fma_mix_f32 (all f32)", w);
         run<2>("v_cvt_f32_f16 (+sdwa WORD_1)", w); run<3>("v_cvt_pkrtz_f16_f32", w); run<4>("v_cvt_pk_f16_f32", w);
-        run<5>("v_dot2c_f32_f16", w); run<7>("fma/mul/fma/add f32", w);
+        run<5>("v_dot2c_f32_f16", w); run<7>("fma/mul/fma/add f32", w); run<8>("v_lshlrev/v_and/v_add_u32/v_perm", w);
     }
     return 0;
 }
