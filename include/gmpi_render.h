@@ -61,7 +61,9 @@ enum {
     GMPI_VARIANT_AUTO = 0,
     GMPI_VARIANT_GATHER = 1, /* one pixel per lane, taps straight from global memory (any shape/stride) */
     GMPI_VARIANT_LDS = 2,    /* pixel tiles, texel boxes staged through LDS with 16-byte row loads      */
-    GMPI_VARIANT_WAVE = 3    /* wave-private 32x8 pixel strips, whole RGBA texels (fp32 / fp16) in LDS  */
+    GMPI_VARIANT_WAVE = 3,   /* wave-private 32x8 pixel strips, whole RGBA texels (fp32 / fp16) in LDS  */
+    GMPI_VARIANT_DMA = 4,    /* pixel tiles, raw texel boxes moved HBM -> LDS by the LDS-DMA path (bf16 / fp32 volumes) */
+    GMPI_VARIANT_BAND = 5    /* 256 x 8 pixel bands, 4 pixels per thread, LDS-DMA loader (bf16 / fp32 volumes)            */
 };
 
 enum {

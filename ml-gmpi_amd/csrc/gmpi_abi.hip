@@ -16,6 +16,10 @@ bool lds_variant_supports(const KParams& p, int dtype);                     // r
 int lds_variant_query(int what);                                            // render_lds.hip
 hipError_t launch_wave(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_wave.hip
 bool wave_variant_supports(const KParams& p, int dtype);                    // render_wave.hip
+hipError_t launch_dma(const KParams& p, int dtype, int tune, hipStream_t stream);   // render_dma.hip
+bool dma_variant_supports(const KParams& p, int dtype);                     // render_dma.hip
+hipError_t launch_band(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_band.hip
+bool band_variant_supports(const KParams& p, int dtype);                    // render_band.hip
 
 // ---- min/max of the normalised grid on the last plane (mpi.py:103-109 diagnostics) --------------
 template <bool AC>
@@ -291,6 +295,14 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         if (!lds_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
         return hip_rc(launch_lds(p, params->rgba_dtype, tune, st));
     }
+    if (variant == GMPI_VARIANT_BAND) {
+        if (!band_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
+        return hip_rc(launch_band(p, params->rgba_dtype, tune, st));
+    }
+    if (variant == GMPI_VARIANT_DMA) {
+        if (!dma_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
+        return hip_rc(launch_dma(p, params->rgba_dtype, tune, st));
+    }
     return GMPI_E_VARIANT;
 }
 
@@ -410,6 +422,8 @@ int gmpi_query(int32_t what) {
         case 2: return 950;
         case 3: case 4: case 5: return lds_variant_query(what);
         case 6: return 1;  // GMPI_VARIANT_WAVE is built in
+        case 7: return 1;  // GMPI_VARIANT_DMA is built in
+        case 8: return 1;  // GMPI_VARIANT_BAND is built in
         default: return -1;
     }
 }

@@ -1,0 +1,611 @@
+// render_band.hip -- GMPI_VARIANT_BAND: 256 x 8 pixel bands, 4 pixels per thread, texel boxes moved HBM -> LDS by the LDS-DMA path.
+//
+// Why (round 3).  Two measurements decide the shape (profiles/r03_band_loader.txt, r03_probe.txt):
+//  * the MEMORY side of a tile decomposition depends on how long the contiguous pieces are that a workgroup asks for in one plane
+//    step: with nothing but the loads running, 32 x 16 pixel tiles (80-byte pieces of a bf16 volume) take 0.92 ms for BASELINE
+//    config 3 however deep the prefetch and however the loads are issued (dword loads, 16-byte loads, LDS-DMA: the same), 128 x 8
+//    bands 0.78-0.80 ms, 256 x 8 bands (528-byte pieces, the rows of a box fill whole 128-byte lines) 0.56 ms = the rate of a
+//    streaming read -- at 2 or 3 workgroups of 512 threads per CU;
+//  * the COMPUTE side is bound by instruction issue and by what a plane step costs besides the pixels: the coordinate chain,
+//    16 taps, bilinear and blend are 55 VALU instructions per pixel and plane (51 of them in the 1.0-1.1 ns class), but a 32 x 16
+//    tile kernel pays 19 VALU + 41 SALU + a barrier per 64 pixels on top (loader, range check, table reads).
+// So: a workgroup of 512 threads owns a 256 x 8 pixel band = 4 sub-blocks of 64 x 8 pixels; two waves per sub-block, every thread
+// 4 pixels (column x, rows j, j+2, j+4, j+6): the per-plane overhead is paid once per 256 pixels of a wave, and the 4 pixels are
+// software-pipelined by hand (taps of pixel p in flight while the coordinate chain of pixel p+1 issues), which is what hides the
+// LDS round trip at 4 waves per SIMD.  Each sub-block has its own texel box (a tilted camera shears the band: one box would be
+// up to 54 rows tall, the sub-blocks' boxes 6-14), staged exactly as in render_dma.hip: raw texels, planar [row][channel][x],
+// one DMA item = 16 bytes of a channel row, lane-linear LDS image, exec-masked DMA instructions, zeros padding by the buffer
+// range check, one s_barrier per plane, taps by ds_read_u16_d16_hi (bf16: the loaded half IS the fp32 value) / ds_read2_b32.
+// A band whose boxes do not fit is rendered in 2 or 4 row groups (64 x 4 / 64 x 2 pixel sub-blocks), then by the direct gather.
+// Arithmetic: gmpi_device.hpp (bit-identical to the oracle in strict-order mode).
+#include "gmpi_device.hpp"
+
+#include <type_traits>
+
+namespace gmpi {
+namespace band {
+
+constexpr int kNT = 1024;              // threads per workgroup (16 wavefronts)
+constexpr int NSB = 4;                 // sub-blocks per band
+constexpr int SBW = 64, SBH = 8;       // sub-block: 64 x 8 pixels = 4 waves x 2 pixels per thread
+constexpr int PPT = 2;                 // pixels per thread: rows j, j + 4 of the sub-block (j = wave % 4)
+constexpr int WPS = SBH / PPT;         // waves per sub-block
+constexpr int kSubLanes = 64 * WPS;    // loader lanes per sub-block
+constexpr int kChunk = 24;             // planes per geometry-table refill (LDS: 2 workgroups per CU)
+constexpr float kBoxEps = 1.0f / 64;
+constexpr float kCoordLimit = 16384.0f;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int V> using ic = std::integral_constant<int, V>;
+
+template <typename TexT> struct Geo {
+    static constexpr int kES = static_cast<int>(sizeof(TexT));
+    static constexpr int kTPI = 16 / kES;                   // texels per 16-byte item
+    static constexpr int kCols = kES == 2 ? 10 : 20;        // items per (row, channel) line: 80 texels
+    static constexpr int kLineBytes = kCols * 16;
+    static constexpr int kRowBytes = 4 * kLineBytes;
+    static constexpr int kIPR = 4 * kCols;                  // items per texel row
+    static constexpr int kMaxRows = kES == 2 ? 14 : 7;      // rows per sub-block buffer
+    static constexpr int kCapItems = kMaxRows * kIPR;
+    static constexpr int kSubBytes = kCapItems * 16;        // 8960
+    static constexpr int kBufBytes = NSB * kSubBytes;
+    // One DMA pass of a sub-block's lanes moves kRPP whole texel rows (lanes beyond kRPP * kIPR idle): a lane's item of pass r is its item
+    // of pass 0 moved down by r * kRPP rows -- one per-lane offset register, the pass in the instruction's scalar offset.
+    static constexpr int kRPP = kSubLanes / kIPR;           // 6 (bf16) / 3 (fp32) rows per pass
+    static constexpr int kPassItems = kRPP * kIPR;          // 240 active lanes
+    static constexpr int kNP = (kMaxRows + kRPP - 1) / kRPP;  // DMA passes per plane at most: 3
+    static constexpr int kRecBytes = 48;                    // per (plane, sub-block): three 16-byte parts L | F | G
+    static constexpr int kTabBytes = kChunk * NSB * kRecBytes;
+    static constexpr int kOffBytes = kNT * 4;               // per-lane loader offsets (kept in LDS: a VGPR through the plane loop is dearer)
+    static constexpr int kLdsBytes = kTabBytes + kOffBytes + 2 * kBufBytes;
+};
+static_assert(Geo<bf16_t>::kLdsBytes * 2 <= 160 * 1024 && Geo<float>::kLdsBytes * 2 <= 160 * 1024, "2 workgroups per CU");
+
+// One DMA instruction: lanes of `mask` move 16 bytes each from (descriptor base + voff + soff) to LDS byte M0 + 16 * lane.
+// (s_nop: an s_mov to M0 needs one wait state before an LDS-DMA reads it.)
+__device__ __forceinline__ void dma16(uint32_t voff, uint32_t soff, const u32x4& rsrc, uint32_t lds_dst, uint64_t mask) {
+    uint64_t save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %4\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %5 offen lds\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(mask), "s"(soff) : "memory");
+}
+// The (up to) three passes of a plane's box in one statement: 11 scalar instructions.  Pass r: lanes m[r], scalar offset r * pass_off,
+// LDS destination lds_dst + D0 + r * STEP (D0, STEP compile-time).  A pass the box does not need has an empty mask.
+template <int D0, int STEP>
+__device__ __forceinline__ void dma16x3(uint32_t voff, uint32_t soff1, uint32_t soff2, const u32x4& rsrc, uint32_t lds_dst, uint64_t m0, uint64_t m1, uint64_t m2) {
+    uint64_t save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %4\n\ts_add_i32 m0, %3, %9\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                 "s_mov_b64 exec, %5\n\ts_add_i32 m0, %3, %10\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %7 offen lds\n\t"
+                 "s_mov_b64 exec, %6\n\ts_add_i32 m0, %3, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %8 offen lds\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(m0), "s"(m1), "s"(m2), "s"(soff1), "s"(soff2), "i"(D0), "i"(D0 + STEP), "i"(D0 + 2 * STEP)
+                 : "memory", "scc");
+}
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (a d16_hi load zeroes the low half of its destination on gfx950: tools/ubench/r3_probe.hip `sem`)
+template <int O> __device__ __forceinline__ void tap16(uint32_t& t, uint32_t a) {
+    asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(t) : "v"(a), "i"(O));
+}
+template <int O> __device__ __forceinline__ void tap32x2(uint32_t& t0, uint32_t& t1, uint32_t a) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 v;
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(a), "i"(O), "i"(O + 1));
+    t0 = v.x, t1 = v.y;
+}
+
+template <typename TexT, bool AC, bool STRICT, bool CHECK>
+__global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy) {
+    using G = Geo<TexT>;
+    constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kNP = G::kNP;
+    constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
+    constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
+    constexpr bool BF = kES == 2;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::kLdsBytes];
+    // record [t][sb]:  L = box origin lo, hi, dims, ext  |  F = zdiff, hw, hh, 1/hw  |  G = 1/hh, tap address constant
+    int4* rec = reinterpret_cast<int4*>(smem);
+    constexpr int kRecBytes = G::kRecBytes;
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kTabBytes + G::kOffBytes)));
+    const uint32_t goff_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kTabBytes)));
+
+    // ---- blockIdx -> band: XCD x = blockIdx % 8 gets a contiguous run of bands (row-major: neighbours share halo rows in one L2) ----
+    const int per_xcd = (n_bands + 7) / 8;
+    const int band_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (band_id >= n_bands) return;
+    const int per_view = bands_x * bands_y;
+    int n, brem;
+    if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) {  // views that share one MPI are interleaved per band position
+        const int group = band_id / (per_view * p.views_per_mpi);
+        const int first = group * p.views_per_mpi, size = min(p.views_per_mpi, p.N - first);
+        const int r = band_id - first * per_view;
+        brem = r / size;
+        n = first + (r - brem * size);
+    } else {
+        n = band_id / per_view;
+        brem = band_id - n * per_view;
+    }
+    const int byi = brem / bands_x, bxi = brem - byi * bands_x;
+
+    const int tid = threadIdx.x;
+    // Registers are the scarce resource (64 per lane for 8 waves per SIMD): values that only depend on the thread index are
+    // recomputed from a laundered copy of it where they are needed, so that they do not live through the plane loop.
+    auto fresh_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sb = wave / WPS, wj = wave % WPS;  // sub-block of this wave, its first pixel row in the sub-block
+    const int lane = tid & 63;
+    // status bits: kept wave-uniform (a scalar register) until the epilogue -- a per-lane word would cost a VGPR through the plane loop
+    uint32_t bad_w = 0;
+    const int m = view_mpi(p, n, bad_w);
+    const int D = p.D, Ht = p.Ht, Wt = p.Wt, H = p.H, W = p.W;
+    const float* __restrict__ dhw = p.dhw + static_cast<int64_t>(m) * D * 3;
+    const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
+    const float zx = p.z_dir[3 * n + 0], zy = p.z_dir[3 * n + 1], zz = p.z_dir[3 * n + 2];
+    // cx, cy: (Wt - 1) / 2, (Ht - 1) / 2 (align_corners) or Wt, Ht -- kernel arguments, i.e. scalar registers: computed here they would sit in
+    // a VGPR each through the plane loop
+    constexpr bool check_range = CHECK;  // GMPI_FLAG_CHECK_RANGE (a template parameter: the test would sit in the plane loop)
+    const bool check_last = (p.flags & (1u << 2)) != 0;
+    const int64_t HW = static_cast<int64_t>(H) * W;
+    const float* __restrict__ rdv = p.ray_dir + static_cast<int64_t>(n) * 3 * HW;
+    const TexT* __restrict__ vol = static_cast<const TexT*>(p.rgba) + static_cast<int64_t>(m) * p.s_mpi;
+    const int64_t s_chan = p.s_chan, s_row = p.s_row, s_plane = p.s_plane;
+
+    if (p.status != nullptr && brem == 0 && tid == 0) {  // mpi.py:70-72, once per view
+        const float ez0 = p.eye_pos[2];
+        bool behind = false;
+        for (int k = 0; k < D; ++k) behind |= !(dhw[3 * k] >= ez0);
+        if (behind) atomicOr(p.status, 4u);
+    }
+
+    // ---- this thread's pixels: column px, rows py0 + WPS q (out-of-image pixels shadow the last row / column) ------------
+    const int px = bxi * (NSB * SBW) + sb * SBW + lane;
+    const int py0 = byi * SBH + wj;
+    const int pxc = min(px, W - 1);
+    float rx[PPT], ry[PPT], rz[PPT], rcp_rz[PPT];
+    Accum A[PPT];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int64_t pix = static_cast<int64_t>(min(py0 + WPS * q, H - 1)) * W + pxc;
+        rx[q] = rdv[pix], ry[q] = rdv[HW + pix], rz[q] = rdv[2 * HW + pix];
+        rcp_rz[q] = 1.0f / rz[q];  // correctly rounded; hoisted out of the plane loop (div_by_recip)
+    }
+    auto ray_dot = [&](int q) {  // einsum("nchw,nc->nhw") mpi.py:149
+        float dot = rx[q] * zx;
+        dot = dot + ry[q] * zy;
+        dot = dot + rz[q] * zz;
+        return dot;
+    };
+    // corner pixels of the sub-block (for the per-plane texel boxes)
+    const int sx0 = min(bxi * (NSB * SBW), W - 1), sy0 = byi * SBH;
+
+    // ---- this thread's loader items: item 128 r + (tid % 128) of its sub-block's box -> (texel row, channel, item column) ----
+    auto loader_pos = [&](int& l_col, int& l_line, int& l_row, bool& l_on) {  // pass 0: line = 4 row + channel
+        const int t = fresh_tid() & (kSubLanes - 1);
+        l_line = t / kCols, l_col = t - l_line * kCols, l_row = l_line >> 2, l_on = t < kPassItems;
+    };
+    {  // byte offset of this lane's pass-0 item from the box origin: parked in LDS, read back with the per-plane burst
+        int l_col, l_line, l_row;
+        bool l_on;
+        loader_pos(l_col, l_line, l_row, l_on);
+        reinterpret_cast<uint32_t*>(smem + G::kTabBytes)[tid] = static_cast<uint32_t>(l_row * s_row + (l_line & 3) * s_chan + kTPI * l_col) * static_cast<uint32_t>(kES);
+    }
+    const uint32_t pass_off = static_cast<uint32_t>(kRPP * s_row) * static_cast<uint32_t>(kES), pass_off2 = 2 * pass_off;           // per pass
+    const uint32_t sub_base = tile_base + static_cast<uint32_t>(sb * kSubBytes);
+    const uint32_t wave_dst = sub_base + static_cast<uint32_t>(wj) * 1024u;  // pass r: + r * kPassItems * 16
+
+#ifdef GMPI_TUNE
+    const bool abl_noload = (p.flags & (1u << 16)) != 0, abl_nocomp = (p.flags & (1u << 17)) != 0, abl_noissue = (p.flags & (1u << 18)) != 0;
+#else
+    constexpr bool abl_noload = false, abl_nocomp = false, abl_noissue = false;
+#endif
+
+#ifdef GMPI_PROF
+    uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prof_last, prof_start;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_start));
+    prof_last = prof_start;
+#endif
+    for (int kc = 0; kc < D; kc += kChunk) {
+        const int kn = min(kChunk, D - kc);
+        // ---- per (plane, sub-block) geometry for the pixel rows [sy0 + r_lo, sy0 + r_hi] of the band -----------------------------
+        auto build_table = [&](int r_lo, int r_hi) -> bool {
+            __syncthreads();  // the previous table and the staging buffers are no longer read
+            bool unfit = false;
+            if (tid < kn * NSB) {
+                const int t = tid / NSB, b = tid - t * NSB, k = kc + t;
+                const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
+                const float zdiff = d - ez;
+                const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
+                const int bx0p = min(sx0 + b * SBW, W - 1), bx1p = min(sx0 + b * SBW + SBW - 1, W - 1);
+                const int by0p = min(sy0 + r_lo, H - 1), by1p = min(sy0 + r_hi, H - 1);
+                float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
+                bool finite = true;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t q = static_cast<int64_t>((c & 2) ? by1p : by0p) * W + ((c & 1) ? bx1p : bx0p);
+                    float ix, iy, s, u, v;
+                    plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, s, u, v);
+                    finite = finite && (fabsf(ix) < kCoordLimit) && (fabsf(iy) < kCoordLimit);  // false for NaN too
+                    mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
+                }
+                int qx0 = 0, by0 = 0, nq = -1, nrows = 0;
+                if (finite) {
+                    const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
+                    by0 = static_cast<int>(floorf(mny - kBoxEps));
+                    const int by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
+                    qx0 = bx0 & ~(kTPI - 1);
+                    nq = (bx1 - qx0) / kTPI + 1;
+                    nrows = by1 - by0 + 1;
+                    if (nq > kCols || nrows > kMaxRows) nq = -1;
+                }
+                unfit = nq < 0;
+                // dims = items per line | rows << 8, sign bit set when part of the box lies outside the texture (zeros padding: the
+                // loader then takes the predicated form); ext = the in-texture item columns [clo, clo + ncol) and rows [rlo, rlo + nrow)
+                int dims = 0, ext = 0;
+                if (nq > 0) {  // (qx0 and Wt are multiples of the item width)
+                    const int clo = min(max(-qx0 / kTPI, 0), nq), chi = min(max((Wt - qx0) / kTPI, 0), nq);
+                    const int rlo = min(max(-by0, 0), nrows), rhi = min(max(Ht - by0, 0), nrows);
+                    const bool inside = clo == 0 && chi == nq && rlo == 0 && rhi == nrows;
+                    dims = nq | nrows << 8 | (inside ? 0 : static_cast<int>(0x80000000u));
+                    ext = clo | (chi - clo) << 8 | rlo << 16 | (rhi - rlo) << 24;
+                } else {
+                    qx0 = 0, by0 = 0;
+                }
+                const uint64_t origin = reinterpret_cast<uint64_t>(vol + (static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(by0) * s_row + qx0));
+                rec[3 * tid + 0] = make_int4(static_cast<int>(origin & 0xffffffffu), static_cast<int>((origin >> 32) & 0xffffu), dims, ext);
+                rec[3 * tid + 1] = make_int4(__float_as_int(zdiff), __float_as_int(hw), __float_as_int(hh), __float_as_int(1.0f / hw));
+                // tap byte address = buffer + (iy0 - by0) * kRowBytes + (ix0 - qx0) * kES, formed in fp32 (all terms are integers below 2^24)
+                const int c0 = static_cast<int>(tile_base) + (t & 1) * kBufBytes + b * kSubBytes - (by0 * kRowBytes + qx0 * kES);
+                rec[3 * tid + 2] = make_int4(__float_as_int(1.0f / hh), __float_as_int(static_cast<float>(c0)), 0, 0);
+            }
+            return __syncthreads_or(unfit) != 0;  // table published; does some box exceed its staging buffer?
+        };
+
+        // ---- last resort (texture much finer than the image, degenerate rays): direct gather, same arithmetic ----------------
+        auto gather_chunk = [&](int g, int ng) {
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                if ((wj + WPS * q) * ng / SBH != g) continue;
+                const float dot = ray_dot(q);
+                for (int t = 0; t < kn; ++t) {
+                    const int4 ri = rec[3 * (t * NSB) + 1];
+                    const float4 rf = make_float4(__int_as_float(ri.x), __int_as_float(ri.y), __int_as_float(ri.z), __int_as_float(ri.w));
+                    float ix, iy, s, u, v;
+                    plane_coord<AC>(rf.x, rf.z + rf.z, rf.y + rf.y, ex, ey, rx[q], ry[q], rz[q], cx, cy, ix, iy, s, u, v);
+                    float smp[4];
+                    uint32_t gbad = 0;
+                    gather_sample<TexT, STRICT>(vol + static_cast<int64_t>(kc + t) * s_plane, s_chan, s_row, Ht, Wt, ix, iy, check_range, gbad, smp);
+                    if (check_range && __any(gbad != 0)) bad_w |= 2u;
+                    blend<STRICT>(A[q], smp[0], smp[1], smp[2], smp[3], s, dot);
+                }
+            }
+        };
+
+        auto run_staged = [&](int g, int ng) {
+            // which of this thread's pixels belong to row group g of ng (wave-uniform)
+            bool on[PPT];
+            float dots[PPT];
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {
+                on[q] = (wj + WPS * q) * ng / SBH == g;
+                dots[q] = STRICT ? ray_dot(q) : 0.0f;  // (default mode applies the dot product once, at the end)
+            }
+            // ---- per wave: exec masks / pass count of the box of the plane last issued (recomputed when the box shape changes: a handful
+            //      of times per chunk).  The range check of plane t runs BEFORE plane t + 1 is issued, so it sees plane t's masks. ----
+            uint64_t m_cur[kNP];
+            int np_cur = 0, dims_cur = 0;
+#pragma unroll
+            for (int r = 0; r < kNP; ++r) m_cur[r] = 0;
+
+            auto issue = [&](const u32x4& rl, uint32_t g_off, auto ub) {  // DMA of the plane with record part L = rl into buffer U (this wave's part of its sub-block's box)
+                constexpr int U = decltype(ub)::value;
+                const uint32_t b_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rl.x)));
+                const uint32_t b_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rl.y)));
+                const int dims = __builtin_amdgcn_readfirstlane(static_cast<int>(rl.z));
+                const u32x4 rsrc = {b_lo, b_hi, 0x80000000u, 0x00020000u};  // raw buffer, num_records 2^31: only the explicit offset below is rejected
+                const uint32_t dst = wave_dst + static_cast<uint32_t>(U * kBufBytes);
+                if (dims >= 0) {  // the box lies inside the texture: lanes of the box load, the others are switched off
+                    if (dims != dims_cur) {
+                        const int nq = dims & 0xff, rows = dims >> 8;
+                        dims_cur = dims;
+                        np_cur = (rows + kRPP - 1) / kRPP;
+                        int l_col, l_line, l_row;
+                        bool l_on;
+                        loader_pos(l_col, l_line, l_row, l_on);
+#pragma unroll
+                        for (int r = 0; r < kNP; ++r) {
+                            m_cur[r] = __ballot(l_on && l_col < nq && l_row + r * kRPP < rows);
+                            if (abl_noload) m_cur[r] = 0;
+                        }
+                    }
+                    static_assert(kNP == 3, "dma16x3");
+                    dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
+                } else {  // zeros padding: every lane of the box rows is active, lanes outside the texture get the out-of-range offset
+                    const int ext = __builtin_amdgcn_readfirstlane(static_cast<int>(rl.w));
+                    const int rows = (dims >> 8) & 0xff;
+                    const uint32_t clo = ext & 0xff, ncol = (ext >> 8) & 0xff, llo = 4 * ((ext >> 16) & 0xff), nline = 4 * ((ext >> 24) & 0xff);
+                    dims_cur = dims;
+                    np_cur = (rows + kRPP - 1) / kRPP;
+                    int l_col, l_line, l_row;
+                    bool l_on;
+                    loader_pos(l_col, l_line, l_row, l_on);
+#pragma unroll
+                    for (int r = 0; r < kNP; ++r) {
+                        m_cur[r] = __ballot(l_on && l_row + r * kRPP < rows);
+                        if (abl_noload) m_cur[r] = 0;
+                        if (r < np_cur) {
+                            const bool ok = (static_cast<uint32_t>(l_col) - clo < ncol) & (static_cast<uint32_t>(l_line + 4 * r * kRPP) - llo < nline);
+                            dma16(ok ? g_off : 0x80000000u, r * pass_off, rsrc, dst + r * (kPassItems * 16), m_cur[r]);
+                        }
+                    }
+                }
+            };
+
+            // ---- [0,1] test of the landed items (mpi.py:185-187): every loader lane reads its own items back (pass R of the plane's box) ----
+            auto check_max = [&](const u32x4& q) -> uint32_t {
+                uint32_t mx;
+                if (BF) {
+                    asm volatile("v_max3_u16 %0, %1, %1, %2 op_sel:[0,1,0,0]\n\tv_max3_u16 %0, %0, %2, %3 op_sel:[0,1,0,0]\n\t"
+                                 "v_max3_u16 %0, %0, %3, %4 op_sel:[0,1,0,0]\n\tv_max3_u16 %0, %0, %4, %4 op_sel:[0,1,0,0]"
+                                 : "=&v"(mx) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+                    mx &= 0xffffu;
+                } else {
+                    asm volatile("v_max3_u32 %0, %1, %2, %3\n\tv_max_u32 %0, %0, %4" : "=&v"(mx) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+                }
+                return mx;
+            };
+            // non-negative patterns order like unsigned integers: in [0,1] <=> pattern <= that of 1.0; the sign bit and NaN/Inf compare above;
+            // -0.0 is legal: exact re-test on the cold path.  Lanes outside the plane's box (empty mask bits) hold stale bytes.
+            auto check_eval3 = [&](const u32x4& q0, const u32x4& q1, const u32x4& q2) {
+                constexpr uint32_t kOne = BF ? 0x3f80u : 0x3f800000u;
+                const uint64_t v0 = __ballot(check_max(q0) > kOne) & m_cur[0], v1 = __ballot(check_max(q1) > kOne) & m_cur[1], v2 = __ballot(check_max(q2) > kOne) & m_cur[2];
+                if (__builtin_expect((v0 | v1 | v2) != 0, 0)) {
+                    const int ln = fresh_tid() & 63;
+                    const u32x4 qs[3] = {q0, q1, q2};
+                    const uint64_t vs[3] = {v0, v1, v2};
+                    bool lane_bad = false;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        if ((vs[r] >> ln) & 1) {
+                            const uint32_t d[4] = {qs[r].x, qs[r].y, qs[r].z, qs[r].w};
+                            if (BF) {
+                                auto ok = [](uint32_t h) { return h <= 0x3f80u || h == 0x8000u; };
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    if (!(ok(d[c] & 0xffffu) && ok(d[c] >> 16))) lane_bad = true;
+                            } else {
+                                auto ok = [](uint32_t e) { return e <= 0x3f800000u || e == 0x80000000u; };
+                                if (!(ok(d[0]) && ok(d[1]) && ok(d[2]) && ok(d[3]))) lane_bad = true;
+                            }
+                        }
+                    if (__any(lane_bad)) bad_w |= 2u;
+                }
+            };
+
+            // ---- one pixel and plane, in three steps so that the taps of pixel q fly while the chain of pixel q + 1 issues ------------
+            struct Coords { float s, nw, ne, sw, se; uint32_t a_tap; };
+            auto coords = [&](int q, const float4& rf, const float2& rg, Coords& c) {
+                float ix, iy, fx, fy;
+                if (STRICT) {
+                    float u, v;
+                    plane_coord<AC>(rf.x, rf.z + rf.z, rf.y + rf.y, ex, ey, rx[q], ry[q], rz[q], cx, cy, ix, iy, c.s, u, v);
+                    fx = floorf(ix), fy = floorf(iy);
+                    const float fx1 = fx + 1.0f, fy1 = fy + 1.0f;
+                    const float wx1 = ix - fx, wx0 = fx1 - ix, wy1 = iy - fy, wy0 = fy1 - iy;
+                    c.nw = wx0 * wy0, c.ne = wx1 * wy0, c.sw = wx0 * wy1, c.se = wx1 * wy1;
+                } else {
+                    plane_coord_recip<AC>(rf.x, rf.y, rf.z, rf.w, rg.x, ex, ey, rx[q], ry[q], rz[q], rcp_rz[q], cx, cy, ix, iy, c.s);
+                    fx = floorf(ix), fy = floorf(iy);
+                    // ATen's vectorised CPU form of the weights: w1 = ix - floor(ix), w0 = 1 - w1
+                    const float wx1 = ix - fx, wy1 = iy - fy;
+                    const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+                    c.nw = wx0 * wy0, c.ne = wx1 * wy0, c.sw = wx0 * wy1, c.se = wx1 * wy1;
+                }
+                // LDS byte address of the north-west tap of channel 0: two exact fp32 FMAs and one saturating conversion (NaN -> 0; an
+                // address past the allocation reads zeros): the box contains every tap of the sub-block (corner argument)
+                const float af = __builtin_fmaf(fy, static_cast<float>(kRowBytes), __builtin_fmaf(fx, static_cast<float>(kES), rg.y));
+                c.a_tap = static_cast<uint32_t>(af);
+            };
+            // The 16 taps of a pixel are fetched as two halves (channels R, G | B, A): 8 tap registers instead of 16 -- what lets two pixels per
+            // thread live in 64 VGPRs without a spill reload in the plane loop (a scratch load shares vmcnt with the DMA: it would drain it).
+            auto taps = [&](auto hb, uint32_t a_tap, uint32_t (&q)[8]) {  // the 8 taps of two channels, landed
+                constexpr int C0 = 2 * decltype(hb)::value;
+                if constexpr (BF) {
+                    asm volatile("ds_read_u16_d16_hi %0, %8 offset:%9\n\tds_read_u16_d16_hi %1, %8 offset:%10\n\tds_read_u16_d16_hi %2, %8 offset:%11\n\tds_read_u16_d16_hi %3, %8 offset:%12\n\t"
+                                 "ds_read_u16_d16_hi %4, %8 offset:%13\n\tds_read_u16_d16_hi %5, %8 offset:%14\n\tds_read_u16_d16_hi %6, %8 offset:%15\n\tds_read_u16_d16_hi %7, %8 offset:%16\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+                                 : "v"(a_tap), "i"(C0 * kLineBytes), "i"(C0 * kLineBytes + 2), "i"(C0 * kLineBytes + kRowBytes), "i"(C0 * kLineBytes + kRowBytes + 2),
+                                   "i"((C0 + 1) * kLineBytes), "i"((C0 + 1) * kLineBytes + 2), "i"((C0 + 1) * kLineBytes + kRowBytes), "i"((C0 + 1) * kLineBytes + kRowBytes + 2));
+                } else {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 v0, v1, v2, v3;
+                    const uint32_t a_bot = a_tap + kRowBytes;
+                    asm volatile("ds_read2_b32 %0, %4 offset0:%6 offset1:%7\n\tds_read2_b32 %1, %5 offset0:%6 offset1:%7\n\t"
+                                 "ds_read2_b32 %2, %4 offset0:%8 offset1:%9\n\tds_read2_b32 %3, %5 offset0:%8 offset1:%9\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                                 : "v"(a_tap), "v"(a_bot), "i"(C0 * (kLineBytes / 4)), "i"(C0 * (kLineBytes / 4) + 1), "i"((C0 + 1) * (kLineBytes / 4)), "i"((C0 + 1) * (kLineBytes / 4) + 1));
+                    q[0] = v0.x, q[1] = v0.y, q[2] = v1.x, q[3] = v1.y, q[4] = v2.x, q[5] = v2.y, q[6] = v3.x, q[7] = v3.y;
+                }
+            };
+            auto pixel = [&](int q, const float4& rf, const float2& rg) {
+                Coords c;
+                coords(q, rf, rg, c);
+                Footprint f;
+                f.nw = c.nw, f.ne = c.ne, f.sw = c.sw, f.se = c.se;
+                uint32_t t[8];
+                float smp[4];
+                taps(ic<0>{}, c.a_tap, t);
+                smp[0] = bilerp<STRICT>(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]), f);
+                smp[1] = bilerp<STRICT>(__uint_as_float(t[4]), __uint_as_float(t[5]), __uint_as_float(t[6]), __uint_as_float(t[7]), f);
+                taps(ic<1>{}, c.a_tap, t);
+                smp[2] = bilerp<STRICT>(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]), f);
+                smp[3] = bilerp<STRICT>(__uint_as_float(t[4]), __uint_as_float(t[5]), __uint_as_float(t[6]), __uint_as_float(t[7]), f);
+                blend<STRICT>(A[q], smp[0], smp[1], smp[2], smp[3], c.s, dots[q]);
+            };
+
+            // One plane step.  Every LDS read the step needs besides the taps is issued in one burst right behind the barrier -- the record part L
+            // of the NEXT plane (for its DMA), this lane's items of the current plane (range check), the parts F, G of the current plane -- and
+            // consumed in that order behind counted waits (LDS operations of a wave return in order): one round trip instead of six.
+            const uint32_t rec_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)smem)) + static_cast<uint32_t>(sb * kRecBytes);
+#ifdef GMPI_PROF  // per-phase shader-clock totals of one wave (status words 8..): barrier | LDS burst | range check | DMA issue | F,G read | pixel 0 | pixel 1
+#define GMPI_STAMP(i) do { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); prof_acc[i] += static_cast<uint32_t>(now_ - prof_last); prof_last = now_; } while (0)
+#else
+#define GMPI_STAMP(i) do { } while (0)
+#endif
+            auto stage = [&](int tt, auto ub) {  // plane tt of the chunk, held by buffer U
+                constexpr int U = decltype(ub)::value;
+                wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
+                GMPI_STAMP(0);
+                uint32_t a_rec = rec_base + static_cast<uint32_t>(tt) * (NSB * kRecBytes);
+                const uint32_t a_it = sub_base + static_cast<uint32_t>(fresh_tid() & (kSubLanes - 1)) * 16u;
+                // (loads and their wait in ONE statement: the compiler may copy an asm load's destination as soon as the statement ends)
+                u32x4 rl, cq0, cq1, cq2;
+                uint32_t g_off;
+                const uint32_t a_g = goff_base + (static_cast<uint32_t>(fresh_tid()) << 2);
+                asm volatile("ds_read_b128 %0, %5 offset:%8\n\tds_read_b32 %4, %7\n\tds_read_b128 %1, %6 offset:%9\n\tds_read_b128 %2, %6 offset:%10\n\tds_read_b128 %3, %6 offset:%11\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(rl), "=&v"(cq0), "=&v"(cq1), "=&v"(cq2), "=&v"(g_off)
+                             : "v"(a_rec), "v"(a_it), "v"(a_g), "i"(NSB * kRecBytes), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16),
+                               "i"(U * kBufBytes + (kNP > 2 ? 2 : 1) * kPassItems * 16));
+                GMPI_STAMP(1);
+                if (check_range) check_eval3(cq0, cq1, cq2);  // (passes the box does not use have empty masks)
+                GMPI_STAMP(2);
+                if (tt + 1 < kn && !abl_noissue) issue(rl, g_off, ic<1 - U>{});
+                GMPI_STAMP(3);
+                // the plane constants of the compositor (F, G parts of this plane's record)
+                u32x4 rfi;
+                uint64_t rgi;
+                asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b64 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rfi), "=&v"(rgi) : "v"(a_rec));
+                const float4 rf = make_float4(__uint_as_float(rfi.x), __uint_as_float(rfi.y), __uint_as_float(rfi.z), __uint_as_float(rfi.w));
+                const float2 rg = make_float2(__uint_as_float(static_cast<uint32_t>(rgi)), __uint_as_float(static_cast<uint32_t>(rgi >> 32)));
+                GMPI_STAMP(4);
+                if (!abl_nocomp) {
+#pragma unroll
+                    for (int q = 0; q < PPT; ++q) {
+                        if (on[q]) pixel(q, rf, rg);  // (the LDS round trips of the taps are covered by the other waves of the SIMD: 8 are resident)
+                        GMPI_STAMP(5 + q);
+                    }
+                }
+                static_assert(PPT == 2 && kNP <= 3, "pixel slots / check passes");
+            };
+            // (live-range split: the per-pixel state may be spilled around the table build, but it must sit in registers through the plane
+            //  loop -- a reload there is a vector memory operation on the DMA's counter)
+#pragma unroll
+            for (int q = 0; q < PPT; ++q)
+                asm volatile("" : "+v"(rx[q]), "+v"(ry[q]), "+v"(rz[q]), "+v"(rcp_rz[q]), "+v"(A[q].T), "+v"(A[q].r), "+v"(A[q].g), "+v"(A[q].b), "+v"(A[q].z));
+            {  // plane 0 of the chunk
+                const int4 r0 = rec[3 * sb];
+                const u32x4 rl0 = {static_cast<uint32_t>(r0.x), static_cast<uint32_t>(r0.y), static_cast<uint32_t>(r0.z), static_cast<uint32_t>(r0.w)};
+                issue(rl0, reinterpret_cast<const uint32_t*>(smem + G::kTabBytes)[fresh_tid()], ic<0>{});
+            }
+            GMPI_STAMP(7);  // (table build, first issue)
+            for (int t = 0; t < kn; t += 2) {
+                stage(t, ic<0>{});
+                if (t + 1 < kn) stage(t + 1, ic<1>{});
+            }
+        };
+
+        // ---- the whole band if every box fits; else in 2, then 4 row groups (boxes rebuilt per group); else the direct gather ------
+        int ng = 1;
+        bool staged_ok = false;
+#pragma unroll 1
+        for (; ng <= 4; ng *= 2) {
+            if (!build_table(0, SBH / ng - 1)) { staged_ok = true; break; }
+        }
+        if (staged_ok) {
+#pragma unroll 1
+            for (int g = 0; g < ng; ++g) {
+                if (byi * SBH + g * (SBH / ng) >= H) break;
+                if (g > 0 && build_table(g * (SBH / ng), (g + 1) * (SBH / ng) - 1)) gather_chunk(g, ng);  // (a later group may still not fit)
+                else run_staged(g, ng);
+            }
+        } else {
+            build_table(0, SBH - 1);
+            gather_chunk(0, 1);
+        }
+    }
+
+    // ---- epilogue per pixel -------------------------------------------------------------------------------------------------
+    uint32_t bad = bad_w;
+    float dl = 0.0f, phl = 1.0f, pwl = 1.0f;
+    if (check_last) dl = dhw[3 * (D - 1) + 0], phl = dhw[3 * (D - 1) + 1], pwl = dhw[3 * (D - 1) + 2];
+    const int px_e = bxi * (NSB * SBW) + sb * SBW + (fresh_tid() & 63);
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+        const int py = byi * SBH + wj + WPS * q;
+        if (check_last) {  // assert_not_out_of_last_plane (mpi.py:381-395): u,v of the last plane, once per pixel
+            float ix, iy, s, u, v;
+            plane_coord<AC>(dl - ez, phl, pwl, ex, ey, rx[q], ry[q], rz[q], cx, cy, ix, iy, s, u, v);
+            if (!(u >= -1.0f && u <= 1.0f && v >= -1.0f && v <= 1.0f)) bad |= 1u;
+        }
+        float r = A[q].r, g = A[q].g, b = A[q].b;
+        if (p.flags & (1u << 1)) {  // mpi_renderer.py:467  2*c - 1
+            r = 2.0f * r - 1.0f;
+            g = 2.0f * g - 1.0f;
+            b = 2.0f * b - 1.0f;
+        }
+        if (px_e < W && py < H) {
+            const int64_t pix = static_cast<int64_t>(py) * W + px_e;
+            float* __restrict__ out = p.rgb_out + static_cast<int64_t>(n) * 3 * HW + pix;
+            out[0] = r;
+            out[HW] = g;
+            out[2 * HW] = b;
+            p.depth_out[static_cast<int64_t>(n) * HW + pix] = finish_depth<STRICT>(A[q], ray_dot(q));
+            if (p.T_out) p.T_out[static_cast<int64_t>(n) * HW + pix] = A[q].T;
+        }
+    }
+    report_status(p.status, bad);
+#ifdef GMPI_PROF
+    if (p.status != nullptr && band_id == 700 && tid == 320) {  // one wave in the middle of the launch
+        uint64_t now_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_));
+        for (int i = 0; i < 8; ++i) p.status[8 + i] = prof_acc[i];
+        p.status[16] = static_cast<uint32_t>(now_ - prof_start);
+    }
+#endif
+}
+
+template <typename TexT>
+static hipError_t launch_t(const KParams& p, hipStream_t stream) {
+    const int bands_x = (p.W + NSB * SBW - 1) / (NSB * SBW), bands_y = (p.H + SBH - 1) / SBH;
+    const int n_bands = bands_x * bands_y * p.N;
+    const dim3 grid(((n_bands + 7) / 8) * 8), block(kNT);
+    const bool acf = p.flags & 1u;
+    const float cx = acf ? static_cast<float>(p.Wt - 1) * 0.5f : static_cast<float>(p.Wt), cy = acf ? static_cast<float>(p.Ht - 1) * 0.5f : static_cast<float>(p.Ht);
+    const int sel = (p.flags & 1u ? 4 : 0) | (p.flags & (1u << 4) ? 2 : 0) | (p.flags & (1u << 3) ? 1 : 0);  // align_corners, strict order, range check
+    switch (sel) {
+#define GMPI_BAND_CASE(I, AC_, ST_, CK_) \
+    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy); break;
+        GMPI_BAND_CASE(0, false, false, false) GMPI_BAND_CASE(1, false, false, true) GMPI_BAND_CASE(2, false, true, false) GMPI_BAND_CASE(3, false, true, true)
+        GMPI_BAND_CASE(4, true, false, false) GMPI_BAND_CASE(5, true, false, true) GMPI_BAND_CASE(6, true, true, false) GMPI_BAND_CASE(7, true, true, true)
+#undef GMPI_BAND_CASE
+    }
+    return hipGetLastError();
+}
+
+}  // namespace band
+
+bool band_variant_supports(const KParams& p, int dtype) {
+    if (dtype == 2) return false;  // fp16 volumes: render_lds.hip (a d16 load yields the half's bits, not an fp32 value)
+    const int es = dtype == 0 ? 4 : 2, tpi = 16 / es;
+    if (p.Wt % tpi != 0) return false;
+    if (reinterpret_cast<uintptr_t>(p.rgba) % 16 != 0) return false;
+    if (p.s_row % tpi != 0 || p.s_chan % tpi != 0 || p.s_plane % tpi != 0 || p.s_mpi % tpi != 0) return false;
+    if (p.Ht > 8192 || p.Wt > 8192) return false;  // tap addresses are formed in fp32
+    const int64_t span = 3 * p.s_chan + 16 * p.s_row + 128;  // the in-plane item offset is kept in 32 bits
+    if (span >= (int64_t(1) << 31) / es) return false;
+    return true;
+}
+
+hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t stream) {
+    KParams p = p0;
+#ifdef GMPI_TUNE  // profiling builds: tune bits 8-9 = ablations (no memory traffic / no compositing)
+    p.flags |= static_cast<uint32_t>((tune >> 8) & 7) << 16;
+#else
+    (void)tune;
+#endif
+    return dtype == 1 ? band::launch_t<bf16_t>(p, stream) : band::launch_t<float>(p, stream);
+}
+
+}  // namespace gmpi

@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
     const size_t es = dt == 0 ? 4 : 2, nvol = (size_t)N * D * 4 * S * S, npix = (size_t)N * S * S;
     void* vol; float *d_dhw, *d_eye, *d_zd, *d_ray, *d_rgb, *d_dep; uint32_t* d_st;
     CK(hipMalloc(&vol, nvol * es)); CK(hipMalloc(&d_dhw, dhw.size() * 4)); CK(hipMalloc(&d_eye, eye.size() * 4)); CK(hipMalloc(&d_zd, zd.size() * 4));
-    CK(hipMalloc(&d_ray, ray.size() * 4)); CK(hipMalloc(&d_rgb, npix * 3 * 4)); CK(hipMalloc(&d_dep, npix * 4)); CK(hipMalloc(&d_st, 16));
+    CK(hipMalloc(&d_ray, ray.size() * 4)); CK(hipMalloc(&d_rgb, npix * 3 * 4)); CK(hipMalloc(&d_dep, npix * 4)); CK(hipMalloc(&d_st, 256));
     CK(hipMemcpy(d_dhw, dhw.data(), dhw.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_eye, eye.data(), eye.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_zd, zd.data(), zd.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ray, ray.data(), ray.size() * 4, hipMemcpyHostToDevice));
     const size_t chan = (size_t)S * S, plane = 4 * chan;
@@ -85,14 +85,15 @@ int main(int argc, char** argv) {
         std::string v = vs.substr(pos, c - pos); pos = c + 1;
         bool strict = false;
         if (v.size() > 2 && v.substr(v.size() - 2) == ":s") strict = true, v = v.substr(0, v.size() - 2);
-        p.variant = v == "gather" ? 1 : v == "lds" ? 2 : v == "wave" ? 3 : 0;
+        p.variant = v == "gather" ? 1 : v == "lds" ? 2 : v == "wave" ? 3 : v == "dma" ? 4 : v == "band" ? 5 : 0;
         p.flags = GMPI_FLAG_ALIGN_CORNERS | GMPI_FLAG_OUT_PM1 | GMPI_FLAG_CHECK_LAST_PLANE | GMPI_FLAG_CHECK_RANGE | (strict ? GMPI_FLAG_STRICT_ORDER : 0);
-        CK(hipMemset(d_st, 0, 16)); CK(hipMemset(d_rgb, 0xff, npix * 12)); CK(hipMemset(d_dep, 0xff, npix * 4));
+        CK(hipMemset(d_st, 0, 256)); CK(hipMemset(d_rgb, 0xff, npix * 12)); CK(hipMemset(d_dep, 0xff, npix * 4));
         int rc = launch(&p, nullptr);
         if (rc != 0) { printf("%-8s rc=%d\n", v.c_str(), rc); continue; }
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(rgb.data(), d_rgb, npix * 12, hipMemcpyDeviceToHost)); CK(hipMemcpy(dep.data(), d_dep, npix * 4, hipMemcpyDeviceToHost));
-        uint32_t st[4]; CK(hipMemcpy(st, d_st, 16, hipMemcpyDeviceToHost));
+        uint32_t st[64]; CK(hipMemcpy(st, d_st, 256, hipMemcpyDeviceToHost));
+        if (st[16]) { printf("  prof (cycles of one wave): total %u | barrier %u burst %u check %u issue %u fg %u px0 %u px1 %u other %u\n", st[16], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15]); }
         float best = 1e9, sum = 0;
         {  // warm-up: ~0.25 s of launches (a GPU coming from idle needs ~0.1 s to reach its busy clocks)
             hipEvent_t w0, w1; CK(hipEventCreate(&w0)); CK(hipEventCreate(&w1));
