@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GMPI_ABI_VERSION 1
+#define GMPI_ABI_VERSION 2
 
 /* storage type of the RGBA volume; arithmetic is always fp32 (mpi_renderer.py:446 `.float()`) */
 enum { GMPI_DTYPE_F32 = 0, GMPI_DTYPE_BF16 = 1, GMPI_DTYPE_F16 = 2 };
@@ -111,7 +111,16 @@ typedef struct GmpiRenderParams {
     float *transmittance_out;/* [N, 1, H, W] or NULL: prod_k (1-a_k+1e-10) -- the cumprod
                                 element the reference slices off at mpi.py:423            */
     uint32_t *status;        /* [GMPI_STATUS_WORDS] or NULL; word 0 is OR-ed with GMPI_STATUS_* */
+
+    void *workspace;         /* device scratch owned by the caller, 256-byte aligned, or NULL.  GMPI_VARIANT_BAND keeps its
+                                per-plane geometry table there (gmpi_render_workspace_bytes() says how much this call
+                                wants); without it GMPI_VARIANT_AUTO uses the kernels that need none.  Contents are
+                                scratch: nothing is carried from one call to the next.                              */
+    uint64_t workspace_bytes;
 } GmpiRenderParams;
+
+/* Bytes of workspace gmpi_mpi_render_launch can make use of for these parameters (0 when no kernel wants any). */
+uint64_t gmpi_render_workspace_bytes(const GmpiRenderParams *params);
 
 /* Enqueue the fused render on `stream`.  Replaces MPI.forward (mpi.py:308-436). */
 int gmpi_mpi_render_launch(const GmpiRenderParams *params, void *stream);

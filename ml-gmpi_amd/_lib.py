@@ -66,6 +66,7 @@ class GmpiRenderParams(ctypes.Structure):
         ("eye_pos", ctypes.c_void_p), ("z_dir", ctypes.c_void_p),
         ("rgb_out", ctypes.c_void_p), ("depth_out", ctypes.c_void_p), ("transmittance_out", ctypes.c_void_p),
         ("status", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64),
     ]
 
 

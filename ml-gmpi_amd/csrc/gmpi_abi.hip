@@ -20,6 +20,7 @@ hipError_t launch_dma(const KParams& p, int dtype, int tune, hipStream_t stream)
 bool dma_variant_supports(const KParams& p, int dtype);                     // render_dma.hip
 hipError_t launch_band(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_band.hip
 bool band_variant_supports(const KParams& p, int dtype);                    // render_band.hip
+uint64_t band_workspace_bytes(const KParams& p);                            // render_band.hip
 
 // ---- min/max of the normalised grid on the last plane (mpi.py:103-109 diagnostics) --------------
 template <bool AC>
@@ -243,6 +244,8 @@ static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, 
     p.N = q->N, p.M = q->M, p.D = q->D, p.Ht = q->Ht, p.Wt = q->Wt, p.H = q->H, p.W = q->W;
     p.views_per_mpi = q->view_to_mpi ? 1 : q->views_per_mpi;
     p.flags = q->flags;
+    p.ws = q->workspace;
+    p.ws_bytes = q->workspace != nullptr ? q->workspace_bytes : 0;
     return GMPI_OK;
 }
 
@@ -304,6 +307,13 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         return hip_rc(launch_dma(p, params->rgba_dtype, tune, st));
     }
     return GMPI_E_VARIANT;
+}
+
+uint64_t gmpi_render_workspace_bytes(const GmpiRenderParams* params) {
+    KParams p;
+    if (to_kparams(params, p, true) != GMPI_OK || p.N == 0) return 0;
+    if (params->rgba_dtype == GMPI_DTYPE_F16) return 0;
+    return band_workspace_bytes(p);
 }
 
 int gmpi_mpi_render_backward_launch(const GmpiRenderParams* params, const float* grad_rgb, const float* grad_depth,

@@ -34,6 +34,8 @@ struct KParams {
     int64_t s_mpi, s_plane, s_chan, s_row;  // element strides of rgba [M,D,4,Ht,Wt] (col stride 1)
     int32_t N, M, D, Ht, Wt, H, W, views_per_mpi;
     uint32_t flags;
+    void* ws;           // caller's workspace (GmpiRenderParams.workspace): the band kernel's geometry table
+    uint64_t ws_bytes;
 };
 
 // MPI sampled by view n: view_to_mpi[n], or n / views_per_mpi.  An index outside [0, M) would address dhw and the volume

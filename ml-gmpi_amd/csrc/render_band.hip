@@ -31,12 +31,15 @@ constexpr int SBW = 64, SBH = 8;       // sub-block: 64 x 8 pixels = 4 waves x 2
 constexpr int PPT = 2;                 // pixels per thread: rows j, j + 4 of the sub-block (j = wave % 4)
 constexpr int WPS = SBH / PPT;         // waves per sub-block
 constexpr int kSubLanes = 64 * WPS;    // loader lanes per sub-block
-constexpr int kChunk = 24;             // planes per geometry-table refill (LDS: 2 workgroups per CU)
 constexpr float kBoxEps = 1.0f / 64;
 constexpr float kCoordLimit = 16384.0f;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int V> using ic = std::integral_constant<int, V>;
+
+// (two passes: boxes of up to 2 * kRPP rows -- the usual case)
+template <int D0, int STEP>
+__device__ __forceinline__ void dma16x2(uint32_t voff, uint32_t soff1, const u32x4& rsrc, uint32_t lds_dst, uint64_t m0, uint64_t m1);
 
 template <typename TexT> struct Geo {
     static constexpr int kES = static_cast<int>(sizeof(TexT));
@@ -45,19 +48,18 @@ template <typename TexT> struct Geo {
     static constexpr int kLineBytes = kCols * 16;
     static constexpr int kRowBytes = 4 * kLineBytes;
     static constexpr int kIPR = 4 * kCols;                  // items per texel row
-    static constexpr int kMaxRows = kES == 2 ? 14 : 7;      // rows per sub-block buffer
+    static constexpr int kMaxRows = kES == 2 ? 15 : 7;      // rows per sub-block buffer
     static constexpr int kCapItems = kMaxRows * kIPR;
-    static constexpr int kSubBytes = kCapItems * 16;        // 8960
+    static constexpr int kSubBytes = kCapItems * 16;        // 9600 (bf16)
     static constexpr int kBufBytes = NSB * kSubBytes;
     // One DMA pass of a sub-block's lanes moves kRPP whole texel rows (lanes beyond kRPP * kIPR idle): a lane's item of pass r is its item
     // of pass 0 moved down by r * kRPP rows -- one per-lane offset register, the pass in the instruction's scalar offset.
     static constexpr int kRPP = kSubLanes / kIPR;           // 6 (bf16) / 3 (fp32) rows per pass
     static constexpr int kPassItems = kRPP * kIPR;          // 240 active lanes
-    static constexpr int kNP = (kMaxRows + kRPP - 1) / kRPP;  // DMA passes per plane at most: 3
-    static constexpr int kRecBytes = 48;                    // per (plane, sub-block): three 16-byte parts L | F | G
-    static constexpr int kTabBytes = kChunk * NSB * kRecBytes;
+    static constexpr int kNP = 3;                           // DMA passes per plane at most
+    static_assert((kMaxRows + kRPP - 1) / kRPP <= kNP, "passes");
     static constexpr int kOffBytes = kNT * 4;               // per-lane loader offsets (kept in LDS: a VGPR through the plane loop is dearer)
-    static constexpr int kLdsBytes = kTabBytes + kOffBytes + 2 * kBufBytes;
+    static constexpr int kLdsBytes = kOffBytes + 2 * kBufBytes;
 };
 static_assert(Geo<bf16_t>::kLdsBytes * 2 <= 160 * 1024 && Geo<float>::kLdsBytes * 2 <= 160 * 1024, "2 workgroups per CU");
 
@@ -81,6 +83,16 @@ __device__ __forceinline__ void dma16x3(uint32_t voff, uint32_t soff1, uint32_t 
                  : "=&s"(save) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(m0), "s"(m1), "s"(m2), "s"(soff1), "s"(soff2), "i"(D0), "i"(D0 + STEP), "i"(D0 + 2 * STEP)
                  : "memory", "scc");
 }
+template <int D0, int STEP>
+__device__ __forceinline__ void dma16x2(uint32_t voff, uint32_t soff1, const u32x4& rsrc, uint32_t lds_dst, uint64_t m0, uint64_t m1) {
+    uint64_t save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %4\n\ts_add_i32 m0, %3, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                 "s_mov_b64 exec, %5\n\ts_add_i32 m0, %3, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %6 offen lds\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(m0), "s"(m1), "s"(soff1), "i"(D0), "i"(D0 + STEP)
+                 : "memory", "scc");
+}
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // (a d16_hi load zeroes the low half of its destination on gfx950: tools/ubench/r3_probe.hip `sem`)
 template <int O> __device__ __forceinline__ void tap16(uint32_t& t, uint32_t a) {
@@ -93,29 +105,10 @@ template <int O> __device__ __forceinline__ void tap32x2(uint32_t& t0, uint32_t&
     t0 = v.x, t1 = v.y;
 }
 
-template <typename TexT, bool AC, bool STRICT, bool CHECK>
-__global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy) {
-    using G = Geo<TexT>;
-    constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kNP = G::kNP;
-    constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
-    constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
-    constexpr bool BF = kES == 2;
-
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G::kLdsBytes];
-    // record [t][sb]:  L = box origin lo, hi, dims, ext  |  F = zdiff, hw, hh, 1/hw  |  G = 1/hh, tap address constant
-    int4* rec = reinterpret_cast<int4*>(smem);
-    constexpr int kRecBytes = G::kRecBytes;
-    typedef __attribute__((address_space(3))) unsigned char lds_byte;
-    const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kTabBytes + G::kOffBytes)));
-    const uint32_t goff_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kTabBytes)));
-
-    // ---- blockIdx -> band: XCD x = blockIdx % 8 gets a contiguous run of bands (row-major: neighbours share halo rows in one L2) ----
-    const int per_xcd = (n_bands + 7) / 8;
-    const int band_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    if (band_id >= n_bands) return;
-    const int per_view = bands_x * bands_y;
-    int n, brem;
-    if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) {  // views that share one MPI are interleaved per band position
+// blockIdx / band index -> view n and band position inside the view.  Views that share one MPI (views_per_mpi > 1) are interleaved per band
+// position, so that the workgroups that need (nearly) the same texels of a plane run next to each other in time and on the same XCD.
+__device__ __forceinline__ void band_to_view(const KParams& p, int band_id, int per_view, int& n, int& brem) {
+    if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) {
         const int group = band_id / (per_view * p.views_per_mpi);
         const int first = group * p.views_per_mpi, size = min(p.views_per_mpi, p.N - first);
         const int r = band_id - first * per_view;
@@ -125,6 +118,101 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         n = band_id / per_view;
         brem = band_id - n * per_view;
     }
+}
+
+// ---- the geometry table: one 64-byte record per (band, plane, sub-block), written by a small kernel in front of the render kernel and read
+//      by the render kernel's waves through scalar loads (no LDS table, no table builds between the planes, no v_readfirstlane):
+//        uint4 L = box origin address lo, hi | dims | ext        uint4 F = zdiff, w/2, h/2, RN(2/w)        uint4 G = RN(2/h), gpart, -, -
+//      dims = items per line | rows << 8, sign bit set when part of the box lies outside the texture (zeros padding: the loader then takes the
+//      predicated form); ext = the in-texture item columns [clo, clo + ncol) and rows [rlo, rlo + nrow); gpart = sub-block's LDS offset minus
+//      the box origin in LDS bytes (tap address = buffer + gpart + iy0 * kRowBytes + ix0 * kES).  hdr[band] != 0: some box of the band does
+//      not fit its staging buffer -> the band takes the direct gather.
+constexpr int kRecU4 = 4;  // uint4 per record
+template <typename TexT, bool AC>
+__global__ __launch_bounds__(256) void band_table_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
+                                                         uint4* __restrict__ recs, uint32_t* __restrict__ hdr) {
+    using G = Geo<TexT>;
+    constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes;
+    const int64_t total = static_cast<int64_t>(n_bands) * p.D * NSB;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = static_cast<int>(i % NSB), k = static_cast<int>((i / NSB) % p.D), band_id = static_cast<int>(i / (static_cast<int64_t>(NSB) * p.D));
+    int n, brem;
+    band_to_view(p, band_id, bands_x * bands_y, n, brem);
+    const int byi = brem / bands_x, bxi = brem - byi * bands_x;
+    uint32_t ignore = 0;
+    const int m = view_mpi(p, n, ignore);
+    const int Ht = p.Ht, Wt = p.Wt, H = p.H, W = p.W;
+    const float* __restrict__ dhw = p.dhw + (static_cast<int64_t>(m) * p.D + k) * 3;
+    const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
+    const int64_t HW = static_cast<int64_t>(H) * W;
+    const float* __restrict__ rdv = p.ray_dir + static_cast<int64_t>(n) * 3 * HW;
+    const TexT* __restrict__ vol = static_cast<const TexT*>(p.rgba) + static_cast<int64_t>(m) * p.s_mpi;
+    const float d = dhw[0], ph = dhw[1], pw = dhw[2];
+    const float zdiff = d - ez;
+    const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
+    const int sx0 = min(bxi * (NSB * SBW), W - 1), sy0 = byi * SBH;
+    const int bx0p = min(sx0 + b * SBW, W - 1), bx1p = min(sx0 + b * SBW + SBW - 1, W - 1);
+    const int by0p = min(sy0, H - 1), by1p = min(sy0 + SBH - 1, H - 1);
+    float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
+    bool finite = true;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {  // the warp is a homography: the box of the sub-block's taps is spanned by its 4 corner pixels
+        const int64_t q = static_cast<int64_t>((c & 2) ? by1p : by0p) * W + ((c & 1) ? bx1p : bx0p);
+        float ix, iy, sc, u, v;
+        plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, sc, u, v);
+        finite = finite && (fabsf(ix) < kCoordLimit) && (fabsf(iy) < kCoordLimit);  // false for NaN too
+        mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
+    }
+    int qx0 = 0, by0 = 0, nq = -1, nrows = 0;
+    if (finite) {
+        const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
+        by0 = static_cast<int>(floorf(mny - kBoxEps));
+        const int by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
+        qx0 = bx0 & ~(kTPI - 1);
+        nq = (bx1 - qx0) / kTPI + 1;
+        nrows = by1 - by0 + 1;
+        if (nq > kCols || nrows > kMaxRows) nq = -1;
+    }
+    int dims = 0, ext = 0;
+    if (nq > 0) {  // (qx0 and Wt are multiples of the item width)
+        const int clo = min(max(-qx0 / kTPI, 0), nq), chi = min(max((Wt - qx0) / kTPI, 0), nq);
+        const int rlo = min(max(-by0, 0), nrows), rhi = min(max(Ht - by0, 0), nrows);
+        const bool inside = clo == 0 && chi == nq && rlo == 0 && rhi == nrows;
+        dims = nq | nrows << 8 | (inside ? 0 : static_cast<int>(0x80000000u));
+        ext = clo | (chi - clo) << 8 | rlo << 16 | (rhi - rlo) << 24;
+    } else {
+        qx0 = 0, by0 = 0;
+        atomicOr(hdr + band_id, 1u);
+    }
+    const uint64_t origin = reinterpret_cast<uint64_t>(vol + (static_cast<int64_t>(k) * p.s_plane + static_cast<int64_t>(by0) * p.s_row + qx0));
+    const int gpart = b * kSubBytes - (by0 * kRowBytes + qx0 * kES);
+    uint4* r = recs + i * kRecU4;
+    r[0] = make_uint4(static_cast<uint32_t>(origin & 0xffffffffu), static_cast<uint32_t>((origin >> 32) & 0xffffu), static_cast<uint32_t>(dims), static_cast<uint32_t>(ext));
+    r[1] = make_uint4(__float_as_uint(zdiff), __float_as_uint(hw), __float_as_uint(hh), __float_as_uint(1.0f / hw));
+    r[2] = make_uint4(__float_as_uint(1.0f / hh), static_cast<uint32_t>(gpart), 0u, 0u);
+}
+
+template <typename TexT, bool AC, bool STRICT, bool CHECK>
+__global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
+                                                         const uint4* __restrict__ recs, const uint32_t* __restrict__ hdr) {
+    using G = Geo<TexT>;
+    constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kNP = G::kNP;
+    constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
+    constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
+    constexpr bool BF = kES == 2;
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::kLdsBytes];
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kOffBytes)));
+    const uint32_t goff_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)smem));
+
+    // ---- blockIdx -> band: XCD x = blockIdx % 8 gets a contiguous run of bands (row-major: neighbours share halo rows in one L2) ----
+    const int per_xcd = (n_bands + 7) / 8;
+    const int band_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (band_id >= n_bands) return;
+    int n, brem;
+    band_to_view(p, band_id, bands_x * bands_y, n, brem);
     const int byi = brem / bands_x, bxi = brem - byi * bands_x;
 
     const int tid = threadIdx.x;
@@ -175,8 +263,6 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         dot = dot + rz[q] * zz;
         return dot;
     };
-    // corner pixels of the sub-block (for the per-plane texel boxes)
-    const int sx0 = min(bxi * (NSB * SBW), W - 1), sy0 = byi * SBH;
 
     // ---- this thread's loader items: item 128 r + (tid % 128) of its sub-block's box -> (texel row, channel, item column) ----
     auto loader_pos = [&](int& l_col, int& l_line, int& l_row, bool& l_on) {  // pass 0: line = 4 row + channel
@@ -187,7 +273,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         int l_col, l_line, l_row;
         bool l_on;
         loader_pos(l_col, l_line, l_row, l_on);
-        reinterpret_cast<uint32_t*>(smem + G::kTabBytes)[tid] = static_cast<uint32_t>(l_row * s_row + (l_line & 3) * s_chan + kTPI * l_col) * static_cast<uint32_t>(kES);
+        reinterpret_cast<uint32_t*>(smem)[tid] = static_cast<uint32_t>(l_row * s_row + (l_line & 3) * s_chan + kTPI * l_col) * static_cast<uint32_t>(kES);
     }
     const uint32_t pass_off = static_cast<uint32_t>(kRPP * s_row) * static_cast<uint32_t>(kES), pass_off2 = 2 * pass_off;           // per pass
     const uint32_t sub_base = tile_base + static_cast<uint32_t>(sb * kSubBytes);
@@ -199,330 +285,267 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
     constexpr bool abl_noload = false, abl_nocomp = false, abl_noissue = false;
 #endif
 
-#ifdef GMPI_PROF
+#ifdef GMPI_PROF  // per-phase shader-clock totals of one wave (status words 8..): barrier | LDS burst | range check | DMA issue | - | pixel 0 | pixel 1
     uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t prof_last, prof_start;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_start));
     prof_last = prof_start;
+#define GMPI_STAMP(i) do { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); prof_acc[i] += static_cast<uint32_t>(now_ - prof_last); prof_last = now_; } while (0)
+#else
+#define GMPI_STAMP(i) do { } while (0)
 #endif
-    for (int kc = 0; kc < D; kc += kChunk) {
-        const int kn = min(kChunk, D - kc);
-        // ---- per (plane, sub-block) geometry for the pixel rows [sy0 + r_lo, sy0 + r_hi] of the band -----------------------------
-        auto build_table = [&](int r_lo, int r_hi) -> bool {
-            __syncthreads();  // the previous table and the staging buffers are no longer read
-            bool unfit = false;
-            if (tid < kn * NSB) {
-                const int t = tid / NSB, b = tid - t * NSB, k = kc + t;
-                const float d = dhw[3 * k + 0], ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
-                const float zdiff = d - ez;
-                const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
-                const int bx0p = min(sx0 + b * SBW, W - 1), bx1p = min(sx0 + b * SBW + SBW - 1, W - 1);
-                const int by0p = min(sy0 + r_lo, H - 1), by1p = min(sy0 + r_hi, H - 1);
-                float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
-                bool finite = true;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int64_t q = static_cast<int64_t>((c & 2) ? by1p : by0p) * W + ((c & 1) ? bx1p : bx0p);
-                    float ix, iy, s, u, v;
-                    plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, s, u, v);
-                    finite = finite && (fabsf(ix) < kCoordLimit) && (fabsf(iy) < kCoordLimit);  // false for NaN too
-                    mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
-                }
-                int qx0 = 0, by0 = 0, nq = -1, nrows = 0;
-                if (finite) {
-                    const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
-                    by0 = static_cast<int>(floorf(mny - kBoxEps));
-                    const int by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
-                    qx0 = bx0 & ~(kTPI - 1);
-                    nq = (bx1 - qx0) / kTPI + 1;
-                    nrows = by1 - by0 + 1;
-                    if (nq > kCols || nrows > kMaxRows) nq = -1;
-                }
-                unfit = nq < 0;
-                // dims = items per line | rows << 8, sign bit set when part of the box lies outside the texture (zeros padding: the
-                // loader then takes the predicated form); ext = the in-texture item columns [clo, clo + ncol) and rows [rlo, rlo + nrow)
-                int dims = 0, ext = 0;
-                if (nq > 0) {  // (qx0 and Wt are multiples of the item width)
-                    const int clo = min(max(-qx0 / kTPI, 0), nq), chi = min(max((Wt - qx0) / kTPI, 0), nq);
-                    const int rlo = min(max(-by0, 0), nrows), rhi = min(max(Ht - by0, 0), nrows);
-                    const bool inside = clo == 0 && chi == nq && rlo == 0 && rhi == nrows;
-                    dims = nq | nrows << 8 | (inside ? 0 : static_cast<int>(0x80000000u));
-                    ext = clo | (chi - clo) << 8 | rlo << 16 | (rhi - rlo) << 24;
-                } else {
-                    qx0 = 0, by0 = 0;
-                }
-                const uint64_t origin = reinterpret_cast<uint64_t>(vol + (static_cast<int64_t>(k) * s_plane + static_cast<int64_t>(by0) * s_row + qx0));
-                rec[3 * tid + 0] = make_int4(static_cast<int>(origin & 0xffffffffu), static_cast<int>((origin >> 32) & 0xffffu), dims, ext);
-                rec[3 * tid + 1] = make_int4(__float_as_int(zdiff), __float_as_int(hw), __float_as_int(hh), __float_as_int(1.0f / hw));
-                // tap byte address = buffer + (iy0 - by0) * kRowBytes + (ix0 - qx0) * kES, formed in fp32 (all terms are integers below 2^24)
-                const int c0 = static_cast<int>(tile_base) + (t & 1) * kBufBytes + b * kSubBytes - (by0 * kRowBytes + qx0 * kES);
-                rec[3 * tid + 2] = make_int4(__float_as_int(1.0f / hh), __float_as_int(static_cast<float>(c0)), 0, 0);
-            }
-            return __syncthreads_or(unfit) != 0;  // table published; does some box exceed its staging buffer?
-        };
 
-        // ---- last resort (texture much finer than the image, degenerate rays): direct gather, same arithmetic ----------------
-        auto gather_chunk = [&](int g, int ng) {
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                if ((wj + WPS * q) * ng / SBH != g) continue;
-                const float dot = ray_dot(q);
-                for (int t = 0; t < kn; ++t) {
-                    const int4 ri = rec[3 * (t * NSB) + 1];
-                    const float4 rf = make_float4(__int_as_float(ri.x), __int_as_float(ri.y), __int_as_float(ri.z), __int_as_float(ri.w));
-                    float ix, iy, s, u, v;
-                    plane_coord<AC>(rf.x, rf.z + rf.z, rf.y + rf.y, ex, ey, rx[q], ry[q], rz[q], cx, cy, ix, iy, s, u, v);
-                    float smp[4];
-                    uint32_t gbad = 0;
-                    gather_sample<TexT, STRICT>(vol + static_cast<int64_t>(kc + t) * s_plane, s_chan, s_row, Ht, Wt, ix, iy, check_range, gbad, smp);
-                    if (check_range && __any(gbad != 0)) bad_w |= 2u;
-                    blend<STRICT>(A[q], smp[0], smp[1], smp[2], smp[3], s, dot);
-                }
-            }
-        };
+    // this wave's records: recs[((band * D + t) * NSB + sb) * 4 + part]
+    const uint4* __restrict__ myrec = recs + (static_cast<int64_t>(band_id) * D * NSB + sb) * kRecU4;
+    constexpr int kRecStep = NSB * kRecU4;  // uint4 from plane t to plane t + 1
 
-        auto run_staged = [&](int g, int ng) {
-            // which of this thread's pixels belong to row group g of ng (wave-uniform)
-            bool on[PPT];
-            float dots[PPT];
+    if (hdr[band_id] != 0) {
+        // ---- last resort (a box does not fit: tilted camera, texture much finer than the image, degenerate rays): direct gather, same arithmetic ----
 #pragma unroll
-            for (int q = 0; q < PPT; ++q) {
-                on[q] = (wj + WPS * q) * ng / SBH == g;
-                dots[q] = STRICT ? ray_dot(q) : 0.0f;  // (default mode applies the dot product once, at the end)
+        for (int q = 0; q < PPT; ++q) {
+            const float dot = ray_dot(q);
+            for (int t = 0; t < D; ++t) {
+                const float d = dhw[3 * t + 0], ph = dhw[3 * t + 1], pw = dhw[3 * t + 2];
+                float ix, iy, s, u, v;
+                plane_coord<AC>(d - ez, ph, pw, ex, ey, rx[q], ry[q], rz[q], cx, cy, ix, iy, s, u, v);
+                float smp[4];
+                uint32_t gbad = 0;
+                gather_sample<TexT, STRICT>(vol + static_cast<int64_t>(t) * s_plane, s_chan, s_row, Ht, Wt, ix, iy, check_range, gbad, smp);
+                if (check_range && __any(gbad != 0)) bad_w |= 2u;
+                blend<STRICT>(A[q], smp[0], smp[1], smp[2], smp[3], s, dot);
             }
-            // ---- per wave: exec masks / pass count of the box of the plane last issued (recomputed when the box shape changes: a handful
-            //      of times per chunk).  The range check of plane t runs BEFORE plane t + 1 is issued, so it sees plane t's masks. ----
-            uint64_t m_cur[kNP];
-            int np_cur = 0, dims_cur = 0;
+        }
+    } else {
+        float dots[PPT];
 #pragma unroll
-            for (int r = 0; r < kNP; ++r) m_cur[r] = 0;
+        for (int q = 0; q < PPT; ++q) dots[q] = STRICT ? ray_dot(q) : 0.0f;  // (default mode applies the dot product once, at the end)
+        // ---- per wave: exec masks / pass count of the box of the plane last issued (recomputed when the box shape changes: a handful of
+        //      times per band).  The range check of plane t runs BEFORE plane t + 1 is issued, so it sees plane t's masks. ----
+        uint64_t m_cur[kNP];
+        int dims_cur = 0;
+        bool three = false;  // the box of the plane last issued needs the third pass
+#pragma unroll
+        for (int r = 0; r < kNP; ++r) m_cur[r] = 0;
 
-            auto issue = [&](const u32x4& rl, uint32_t g_off, auto ub) {  // DMA of the plane with record part L = rl into buffer U (this wave's part of its sub-block's box)
-                constexpr int U = decltype(ub)::value;
-                const uint32_t b_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rl.x)));
-                const uint32_t b_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rl.y)));
-                const int dims = __builtin_amdgcn_readfirstlane(static_cast<int>(rl.z));
-                const u32x4 rsrc = {b_lo, b_hi, 0x80000000u, 0x00020000u};  // raw buffer, num_records 2^31: only the explicit offset below is rejected
-                const uint32_t dst = wave_dst + static_cast<uint32_t>(U * kBufBytes);
-                if (dims >= 0) {  // the box lies inside the texture: lanes of the box load, the others are switched off
-                    if (dims != dims_cur) {
-                        const int nq = dims & 0xff, rows = dims >> 8;
-                        dims_cur = dims;
-                        np_cur = (rows + kRPP - 1) / kRPP;
-                        int l_col, l_line, l_row;
-                        bool l_on;
-                        loader_pos(l_col, l_line, l_row, l_on);
-#pragma unroll
-                        for (int r = 0; r < kNP; ++r) {
-                            m_cur[r] = __ballot(l_on && l_col < nq && l_row + r * kRPP < rows);
-                            if (abl_noload) m_cur[r] = 0;
-                        }
-                    }
-                    static_assert(kNP == 3, "dma16x3");
-                    dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
-                } else {  // zeros padding: every lane of the box rows is active, lanes outside the texture get the out-of-range offset
-                    const int ext = __builtin_amdgcn_readfirstlane(static_cast<int>(rl.w));
-                    const int rows = (dims >> 8) & 0xff;
-                    const uint32_t clo = ext & 0xff, ncol = (ext >> 8) & 0xff, llo = 4 * ((ext >> 16) & 0xff), nline = 4 * ((ext >> 24) & 0xff);
+        auto issue = [&](const uint4& rl, uint32_t g_off, auto ub) {  // DMA of the plane with record part L = rl into buffer U (this wave's part of its sub-block's box)
+            constexpr int U = decltype(ub)::value;
+            const int dims = static_cast<int>(rl.z);
+            const u32x4 rsrc = {rl.x, rl.y, 0x80000000u, 0x00020000u};  // raw buffer, num_records 2^31: only the explicit offset below is rejected
+            if (dims >= 0) {  // the box lies inside the texture: lanes of the box load, the others are switched off
+                if (dims != dims_cur) {
+                    const int nq = dims & 0xff, rows = dims >> 8;
                     dims_cur = dims;
-                    np_cur = (rows + kRPP - 1) / kRPP;
+                    three = rows > 2 * kRPP;
                     int l_col, l_line, l_row;
                     bool l_on;
                     loader_pos(l_col, l_line, l_row, l_on);
 #pragma unroll
                     for (int r = 0; r < kNP; ++r) {
-                        m_cur[r] = __ballot(l_on && l_row + r * kRPP < rows);
+                        m_cur[r] = __ballot(l_on && l_col < nq && l_row + r * kRPP < rows);
                         if (abl_noload) m_cur[r] = 0;
-                        if (r < np_cur) {
-                            const bool ok = (static_cast<uint32_t>(l_col) - clo < ncol) & (static_cast<uint32_t>(l_line + 4 * r * kRPP) - llo < nline);
-                            dma16(ok ? g_off : 0x80000000u, r * pass_off, rsrc, dst + r * (kPassItems * 16), m_cur[r]);
-                        }
                     }
                 }
-            };
-
-            // ---- [0,1] test of the landed items (mpi.py:185-187): every loader lane reads its own items back (pass R of the plane's box) ----
-            auto check_max = [&](const u32x4& q) -> uint32_t {
-                uint32_t mx;
-                if (BF) {
-                    asm volatile("v_max3_u16 %0, %1, %1, %2 op_sel:[0,1,0,0]\n\tv_max3_u16 %0, %0, %2, %3 op_sel:[0,1,0,0]\n\t"
-                                 "v_max3_u16 %0, %0, %3, %4 op_sel:[0,1,0,0]\n\tv_max3_u16 %0, %0, %4, %4 op_sel:[0,1,0,0]"
-                                 : "=&v"(mx) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
-                    mx &= 0xffffu;
-                } else {
-                    asm volatile("v_max3_u32 %0, %1, %2, %3\n\tv_max_u32 %0, %0, %4" : "=&v"(mx) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
-                }
-                return mx;
-            };
-            // non-negative patterns order like unsigned integers: in [0,1] <=> pattern <= that of 1.0; the sign bit and NaN/Inf compare above;
-            // -0.0 is legal: exact re-test on the cold path.  Lanes outside the plane's box (empty mask bits) hold stale bytes.
-            auto check_eval3 = [&](const u32x4& q0, const u32x4& q1, const u32x4& q2) {
-                constexpr uint32_t kOne = BF ? 0x3f80u : 0x3f800000u;
-                const uint64_t v0 = __ballot(check_max(q0) > kOne) & m_cur[0], v1 = __ballot(check_max(q1) > kOne) & m_cur[1], v2 = __ballot(check_max(q2) > kOne) & m_cur[2];
-                if (__builtin_expect((v0 | v1 | v2) != 0, 0)) {
-                    const int ln = fresh_tid() & 63;
-                    const u32x4 qs[3] = {q0, q1, q2};
-                    const uint64_t vs[3] = {v0, v1, v2};
-                    bool lane_bad = false;
+                static_assert(kNP == 3, "dma16x3");
+                if (three) dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
+                else dma16x2<U * kBufBytes, kPassItems * 16>(g_off, pass_off, rsrc, wave_dst, m_cur[0], m_cur[1]);
+            } else {  // zeros padding: every lane of the box rows is active, lanes outside the texture get the out-of-range offset
+                const int ext = static_cast<int>(rl.w);
+                const int rows = (dims >> 8) & 0xff;
+                const uint32_t clo = ext & 0xff, ncol = (ext >> 8) & 0xff, llo = 4 * ((ext >> 16) & 0xff), nline = 4 * ((ext >> 24) & 0xff);
+                dims_cur = dims;
+                three = rows > 2 * kRPP;
+                const int npk = (rows + kRPP - 1) / kRPP;
+                int l_col, l_line, l_row;
+                bool l_on;
+                loader_pos(l_col, l_line, l_row, l_on);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        if ((vs[r] >> ln) & 1) {
-                            const uint32_t d[4] = {qs[r].x, qs[r].y, qs[r].z, qs[r].w};
-                            if (BF) {
-                                auto ok = [](uint32_t h) { return h <= 0x3f80u || h == 0x8000u; };
-#pragma unroll
-                                for (int c = 0; c < 4; ++c)
-                                    if (!(ok(d[c] & 0xffffu) && ok(d[c] >> 16))) lane_bad = true;
-                            } else {
-                                auto ok = [](uint32_t e) { return e <= 0x3f800000u || e == 0x80000000u; };
-                                if (!(ok(d[0]) && ok(d[1]) && ok(d[2]) && ok(d[3]))) lane_bad = true;
-                            }
-                        }
-                    if (__any(lane_bad)) bad_w |= 2u;
-                }
-            };
-
-            // ---- one pixel and plane, in three steps so that the taps of pixel q fly while the chain of pixel q + 1 issues ------------
-            struct Coords { float s, nw, ne, sw, se; uint32_t a_tap; };
-            auto coords = [&](int q, const float4& rf, const float2& rg, Coords& c) {
-                float ix, iy, fx, fy;
-                if (STRICT) {
-                    float u, v;
-                    plane_coord<AC>(rf.x, rf.z + rf.z, rf.y + rf.y, ex, ey, rx[q], ry[q], rz[q], cx, cy, ix, iy, c.s, u, v);
-                    fx = floorf(ix), fy = floorf(iy);
-                    const float fx1 = fx + 1.0f, fy1 = fy + 1.0f;
-                    const float wx1 = ix - fx, wx0 = fx1 - ix, wy1 = iy - fy, wy0 = fy1 - iy;
-                    c.nw = wx0 * wy0, c.ne = wx1 * wy0, c.sw = wx0 * wy1, c.se = wx1 * wy1;
-                } else {
-                    plane_coord_recip<AC>(rf.x, rf.y, rf.z, rf.w, rg.x, ex, ey, rx[q], ry[q], rz[q], rcp_rz[q], cx, cy, ix, iy, c.s);
-                    fx = floorf(ix), fy = floorf(iy);
-                    // ATen's vectorised CPU form of the weights: w1 = ix - floor(ix), w0 = 1 - w1
-                    const float wx1 = ix - fx, wy1 = iy - fy;
-                    const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-                    c.nw = wx0 * wy0, c.ne = wx1 * wy0, c.sw = wx0 * wy1, c.se = wx1 * wy1;
-                }
-                // LDS byte address of the north-west tap of channel 0: two exact fp32 FMAs and one saturating conversion (NaN -> 0; an
-                // address past the allocation reads zeros): the box contains every tap of the sub-block (corner argument)
-                const float af = __builtin_fmaf(fy, static_cast<float>(kRowBytes), __builtin_fmaf(fx, static_cast<float>(kES), rg.y));
-                c.a_tap = static_cast<uint32_t>(af);
-            };
-            // The 16 taps of a pixel are fetched as two halves (channels R, G | B, A): 8 tap registers instead of 16 -- what lets two pixels per
-            // thread live in 64 VGPRs without a spill reload in the plane loop (a scratch load shares vmcnt with the DMA: it would drain it).
-            auto taps = [&](auto hb, uint32_t a_tap, uint32_t (&q)[8]) {  // the 8 taps of two channels, landed
-                constexpr int C0 = 2 * decltype(hb)::value;
-                if constexpr (BF) {
-                    asm volatile("ds_read_u16_d16_hi %0, %8 offset:%9\n\tds_read_u16_d16_hi %1, %8 offset:%10\n\tds_read_u16_d16_hi %2, %8 offset:%11\n\tds_read_u16_d16_hi %3, %8 offset:%12\n\t"
-                                 "ds_read_u16_d16_hi %4, %8 offset:%13\n\tds_read_u16_d16_hi %5, %8 offset:%14\n\tds_read_u16_d16_hi %6, %8 offset:%15\n\tds_read_u16_d16_hi %7, %8 offset:%16\n\t"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
-                                 : "v"(a_tap), "i"(C0 * kLineBytes), "i"(C0 * kLineBytes + 2), "i"(C0 * kLineBytes + kRowBytes), "i"(C0 * kLineBytes + kRowBytes + 2),
-                                   "i"((C0 + 1) * kLineBytes), "i"((C0 + 1) * kLineBytes + 2), "i"((C0 + 1) * kLineBytes + kRowBytes), "i"((C0 + 1) * kLineBytes + kRowBytes + 2));
-                } else {
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    u32x2 v0, v1, v2, v3;
-                    const uint32_t a_bot = a_tap + kRowBytes;
-                    asm volatile("ds_read2_b32 %0, %4 offset0:%6 offset1:%7\n\tds_read2_b32 %1, %5 offset0:%6 offset1:%7\n\t"
-                                 "ds_read2_b32 %2, %4 offset0:%8 offset1:%9\n\tds_read2_b32 %3, %5 offset0:%8 offset1:%9\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
-                                 : "v"(a_tap), "v"(a_bot), "i"(C0 * (kLineBytes / 4)), "i"(C0 * (kLineBytes / 4) + 1), "i"((C0 + 1) * (kLineBytes / 4)), "i"((C0 + 1) * (kLineBytes / 4) + 1));
-                    q[0] = v0.x, q[1] = v0.y, q[2] = v1.x, q[3] = v1.y, q[4] = v2.x, q[5] = v2.y, q[6] = v3.x, q[7] = v3.y;
-                }
-            };
-            auto pixel = [&](int q, const float4& rf, const float2& rg) {
-                Coords c;
-                coords(q, rf, rg, c);
-                Footprint f;
-                f.nw = c.nw, f.ne = c.ne, f.sw = c.sw, f.se = c.se;
-                uint32_t t[8];
-                float smp[4];
-                taps(ic<0>{}, c.a_tap, t);
-                smp[0] = bilerp<STRICT>(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]), f);
-                smp[1] = bilerp<STRICT>(__uint_as_float(t[4]), __uint_as_float(t[5]), __uint_as_float(t[6]), __uint_as_float(t[7]), f);
-                taps(ic<1>{}, c.a_tap, t);
-                smp[2] = bilerp<STRICT>(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]), f);
-                smp[3] = bilerp<STRICT>(__uint_as_float(t[4]), __uint_as_float(t[5]), __uint_as_float(t[6]), __uint_as_float(t[7]), f);
-                blend<STRICT>(A[q], smp[0], smp[1], smp[2], smp[3], c.s, dots[q]);
-            };
-
-            // One plane step.  Every LDS read the step needs besides the taps is issued in one burst right behind the barrier -- the record part L
-            // of the NEXT plane (for its DMA), this lane's items of the current plane (range check), the parts F, G of the current plane -- and
-            // consumed in that order behind counted waits (LDS operations of a wave return in order): one round trip instead of six.
-            const uint32_t rec_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)smem)) + static_cast<uint32_t>(sb * kRecBytes);
-#ifdef GMPI_PROF  // per-phase shader-clock totals of one wave (status words 8..): barrier | LDS burst | range check | DMA issue | F,G read | pixel 0 | pixel 1
-#define GMPI_STAMP(i) do { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)); prof_acc[i] += static_cast<uint32_t>(now_ - prof_last); prof_last = now_; } while (0)
-#else
-#define GMPI_STAMP(i) do { } while (0)
-#endif
-            auto stage = [&](int tt, auto ub) {  // plane tt of the chunk, held by buffer U
-                constexpr int U = decltype(ub)::value;
-                wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
-                GMPI_STAMP(0);
-                uint32_t a_rec = rec_base + static_cast<uint32_t>(tt) * (NSB * kRecBytes);
-                const uint32_t a_it = sub_base + static_cast<uint32_t>(fresh_tid() & (kSubLanes - 1)) * 16u;
-                // (loads and their wait in ONE statement: the compiler may copy an asm load's destination as soon as the statement ends)
-                u32x4 rl, cq0, cq1, cq2;
-                uint32_t g_off;
-                const uint32_t a_g = goff_base + (static_cast<uint32_t>(fresh_tid()) << 2);
-                asm volatile("ds_read_b128 %0, %5 offset:%8\n\tds_read_b32 %4, %7\n\tds_read_b128 %1, %6 offset:%9\n\tds_read_b128 %2, %6 offset:%10\n\tds_read_b128 %3, %6 offset:%11\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(rl), "=&v"(cq0), "=&v"(cq1), "=&v"(cq2), "=&v"(g_off)
-                             : "v"(a_rec), "v"(a_it), "v"(a_g), "i"(NSB * kRecBytes), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16),
-                               "i"(U * kBufBytes + (kNP > 2 ? 2 : 1) * kPassItems * 16));
-                GMPI_STAMP(1);
-                if (check_range) check_eval3(cq0, cq1, cq2);  // (passes the box does not use have empty masks)
-                GMPI_STAMP(2);
-                if (tt + 1 < kn && !abl_noissue) issue(rl, g_off, ic<1 - U>{});
-                GMPI_STAMP(3);
-                // the plane constants of the compositor (F, G parts of this plane's record)
-                u32x4 rfi;
-                uint64_t rgi;
-                asm volatile("ds_read_b128 %0, %2 offset:16\n\tds_read_b64 %1, %2 offset:32\n\ts_waitcnt lgkmcnt(0)" : "=&v"(rfi), "=&v"(rgi) : "v"(a_rec));
-                const float4 rf = make_float4(__uint_as_float(rfi.x), __uint_as_float(rfi.y), __uint_as_float(rfi.z), __uint_as_float(rfi.w));
-                const float2 rg = make_float2(__uint_as_float(static_cast<uint32_t>(rgi)), __uint_as_float(static_cast<uint32_t>(rgi >> 32)));
-                GMPI_STAMP(4);
-                if (!abl_nocomp) {
-#pragma unroll
-                    for (int q = 0; q < PPT; ++q) {
-                        if (on[q]) pixel(q, rf, rg);  // (the LDS round trips of the taps are covered by the other waves of the SIMD: 8 are resident)
-                        GMPI_STAMP(5 + q);
+                for (int r = 0; r < kNP; ++r) {
+                    m_cur[r] = __ballot(l_on && l_row + r * kRPP < rows);
+                    if (abl_noload) m_cur[r] = 0;
+                    if (r < npk) {
+                        const bool ok = (static_cast<uint32_t>(l_col) - clo < ncol) & (static_cast<uint32_t>(l_line + 4 * r * kRPP) - llo < nline);
+                        dma16(ok ? g_off : 0x80000000u, r * pass_off, rsrc, wave_dst + static_cast<uint32_t>(U * kBufBytes + r * (kPassItems * 16)), m_cur[r]);
                     }
                 }
-                static_assert(PPT == 2 && kNP <= 3, "pixel slots / check passes");
-            };
-            // (live-range split: the per-pixel state may be spilled around the table build, but it must sit in registers through the plane
-            //  loop -- a reload there is a vector memory operation on the DMA's counter)
-#pragma unroll
-            for (int q = 0; q < PPT; ++q)
-                asm volatile("" : "+v"(rx[q]), "+v"(ry[q]), "+v"(rz[q]), "+v"(rcp_rz[q]), "+v"(A[q].T), "+v"(A[q].r), "+v"(A[q].g), "+v"(A[q].b), "+v"(A[q].z));
-            {  // plane 0 of the chunk
-                const int4 r0 = rec[3 * sb];
-                const u32x4 rl0 = {static_cast<uint32_t>(r0.x), static_cast<uint32_t>(r0.y), static_cast<uint32_t>(r0.z), static_cast<uint32_t>(r0.w)};
-                issue(rl0, reinterpret_cast<const uint32_t*>(smem + G::kTabBytes)[fresh_tid()], ic<0>{});
-            }
-            GMPI_STAMP(7);  // (table build, first issue)
-            for (int t = 0; t < kn; t += 2) {
-                stage(t, ic<0>{});
-                if (t + 1 < kn) stage(t + 1, ic<1>{});
             }
         };
 
-        // ---- the whole band if every box fits; else in 2, then 4 row groups (boxes rebuilt per group); else the direct gather ------
-        int ng = 1;
-        bool staged_ok = false;
-#pragma unroll 1
-        for (; ng <= 4; ng *= 2) {
-            if (!build_table(0, SBH / ng - 1)) { staged_ok = true; break; }
-        }
-        if (staged_ok) {
-#pragma unroll 1
-            for (int g = 0; g < ng; ++g) {
-                if (byi * SBH + g * (SBH / ng) >= H) break;
-                if (g > 0 && build_table(g * (SBH / ng), (g + 1) * (SBH / ng) - 1)) gather_chunk(g, ng);  // (a later group may still not fit)
-                else run_staged(g, ng);
+        // ---- [0,1] test of the landed items (mpi.py:185-187).  Every loader lane reads its own items back and folds their bit patterns into a
+        //      running unsigned maximum (non-negative floats order like unsigned integers: in [0,1] <=> pattern <= that of 1.0; the sign bit and
+        //      NaN / Inf compare above): 4 (bf16) / 2 (fp32) instructions per 16-byte item, no compare, no branch in the plane loop.  The staging
+        //      buffers are zero-filled once per band, so every byte a lane can read there is zero or a texel that some plane's loader brought in:
+        //      no masks.  The verdict is taken once per band (check_verdict below).
+        uint32_t chk_acc = 0;
+        auto check_fold = [&](const u32x4& q) {
+            if (BF)
+                asm volatile("v_max3_u16 %0, %0, %1, %1 op_sel:[0,0,1,0]\n\tv_max3_u16 %0, %0, %2, %2 op_sel:[0,0,1,0]\n\t"
+                             "v_max3_u16 %0, %0, %3, %3 op_sel:[0,0,1,0]\n\tv_max3_u16 %0, %0, %4, %4 op_sel:[0,0,1,0]"
+                             : "+v"(chk_acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+            else
+                asm volatile("v_max3_u32 %0, %0, %1, %2\n\tv_max3_u32 %0, %0, %3, %4" : "+v"(chk_acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+        };
+
+        // ---- one pixel and plane, in three steps so that the taps of pixel q fly while the chain of pixel q + 1 issues ------------
+        struct Coords { float s, nw, ne, sw, se; uint32_t a_tap; };
+        auto coords = [&](int q, const float4& rf, const float2& rg, Coords& c) {
+            float ix, iy, fx, fy;
+            if (STRICT) {
+                float u, v;
+                plane_coord<AC>(rf.x, rf.z + rf.z, rf.y + rf.y, ex, ey, rx[q], ry[q], rz[q], cx, cy, ix, iy, c.s, u, v);
+                fx = floorf(ix), fy = floorf(iy);
+                const float fx1 = fx + 1.0f, fy1 = fy + 1.0f;
+                const float wx1 = ix - fx, wx0 = fx1 - ix, wy1 = iy - fy, wy0 = fy1 - iy;
+                c.nw = wx0 * wy0, c.ne = wx1 * wy0, c.sw = wx0 * wy1, c.se = wx1 * wy1;
+            } else {
+                plane_coord_recip<AC>(rf.x, rf.y, rf.z, rf.w, rg.x, ex, ey, rx[q], ry[q], rz[q], rcp_rz[q], cx, cy, ix, iy, c.s);
+                fx = floorf(ix), fy = floorf(iy);
+                // ATen's vectorised CPU form of the weights: w1 = ix - floor(ix), w0 = 1 - w1
+                const float wx1 = ix - fx, wy1 = iy - fy;
+                const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+                c.nw = wx0 * wy0, c.ne = wx1 * wy0, c.sw = wx0 * wy1, c.se = wx1 * wy1;
             }
-        } else {
-            build_table(0, SBH - 1);
-            gather_chunk(0, 1);
+            // LDS byte address of the north-west tap of channel 0: two exact fp32 FMAs and one saturating conversion (NaN -> 0; an
+            // address past the allocation reads zeros): the box contains every tap of the sub-block (corner argument)
+            const float af = __builtin_fmaf(fy, static_cast<float>(kRowBytes), __builtin_fmaf(fx, static_cast<float>(kES), rg.y));
+            c.a_tap = static_cast<uint32_t>(af);
+        };
+        // The 16 taps of a pixel are fetched as two halves (channels R, G | B, A): 8 tap registers instead of 16 -- what lets two pixels per
+        // thread live in 64 VGPRs without a spill reload in the plane loop (a scratch load shares vmcnt with the DMA: it would drain it).
+        auto taps = [&](auto hb, uint32_t a_tap, uint32_t (&q)[8]) {  // the 8 taps of two channels, landed
+            constexpr int C0 = 2 * decltype(hb)::value;
+            if constexpr (BF) {
+                asm volatile("ds_read_u16_d16_hi %0, %8 offset:%9\n\tds_read_u16_d16_hi %1, %8 offset:%10\n\tds_read_u16_d16_hi %2, %8 offset:%11\n\tds_read_u16_d16_hi %3, %8 offset:%12\n\t"
+                             "ds_read_u16_d16_hi %4, %8 offset:%13\n\tds_read_u16_d16_hi %5, %8 offset:%14\n\tds_read_u16_d16_hi %6, %8 offset:%15\n\tds_read_u16_d16_hi %7, %8 offset:%16\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+                             : "v"(a_tap), "i"(C0 * kLineBytes), "i"(C0 * kLineBytes + 2), "i"(C0 * kLineBytes + kRowBytes), "i"(C0 * kLineBytes + kRowBytes + 2),
+                               "i"((C0 + 1) * kLineBytes), "i"((C0 + 1) * kLineBytes + 2), "i"((C0 + 1) * kLineBytes + kRowBytes), "i"((C0 + 1) * kLineBytes + kRowBytes + 2));
+            } else {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 v0, v1, v2, v3;
+                const uint32_t a_bot = a_tap + kRowBytes;
+                asm volatile("ds_read2_b32 %0, %4 offset0:%6 offset1:%7\n\tds_read2_b32 %1, %5 offset0:%6 offset1:%7\n\t"
+                             "ds_read2_b32 %2, %4 offset0:%8 offset1:%9\n\tds_read2_b32 %3, %5 offset0:%8 offset1:%9\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                             : "v"(a_tap), "v"(a_bot), "i"(C0 * (kLineBytes / 4)), "i"(C0 * (kLineBytes / 4) + 1), "i"((C0 + 1) * (kLineBytes / 4)), "i"((C0 + 1) * (kLineBytes / 4) + 1));
+                q[0] = v0.x, q[1] = v0.y, q[2] = v1.x, q[3] = v1.y, q[4] = v2.x, q[5] = v2.y, q[6] = v3.x, q[7] = v3.y;
+            }
+        };
+        auto pixel = [&](int q, const float4& rf, const float2& rg) {
+            Coords c;
+            coords(q, rf, rg, c);
+            Footprint f;
+            f.nw = c.nw, f.ne = c.ne, f.sw = c.sw, f.se = c.se;
+            uint32_t t[8];
+            float smp[4];
+            taps(ic<0>{}, c.a_tap, t);
+            smp[0] = bilerp<STRICT>(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]), f);
+            smp[1] = bilerp<STRICT>(__uint_as_float(t[4]), __uint_as_float(t[5]), __uint_as_float(t[6]), __uint_as_float(t[7]), f);
+            taps(ic<1>{}, c.a_tap, t);
+            smp[2] = bilerp<STRICT>(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]), f);
+            smp[3] = bilerp<STRICT>(__uint_as_float(t[4]), __uint_as_float(t[5]), __uint_as_float(t[6]), __uint_as_float(t[7]), f);
+            blend<STRICT>(A[q], smp[0], smp[1], smp[2], smp[3], c.s, dots[q]);
+        };
+
+
+        // One plane step.  The records come through scalar loads issued a step ahead (part L of plane t + 2 for the DMA of the next step,
+        // parts F, G of plane t + 1 for its pixels); this lane's items of the current plane (range check) and its loader offset come in one
+        // LDS burst behind the barrier.
+        uint4 Ln, Fc, Gc;  // wave-uniform: scalar registers
+        auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
+            constexpr int U = decltype(ub)::value;
+            wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
+            GMPI_STAMP(0);
+            const uint32_t a_it = sub_base + static_cast<uint32_t>(fresh_tid() & (kSubLanes - 1)) * 16u;
+            const uint32_t a_g = goff_base + (static_cast<uint32_t>(fresh_tid()) << 2);
+            // (loads and their wait in ONE statement: the compiler may copy an asm load's destination as soon as the statement ends)
+            u32x4 cq0, cq1, cq2;
+            uint32_t g_off;
+            const bool three_cur = three;  // set by the issue of this plane, one step ago
+            if (check_range) {
+                asm volatile("ds_read_b32 %2, %4\n\tds_read_b128 %0, %3 offset:%5\n\tds_read_b128 %1, %3 offset:%6\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(cq0), "=&v"(cq1), "=&v"(g_off)
+                             : "v"(a_it), "v"(a_g), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                GMPI_STAMP(1);
+                check_fold(cq0), check_fold(cq1);
+                if (three_cur) {  // (the box of THIS plane has a third pass: the rest of the sub-block's buffer -- lanes beyond it re-read its first item)
+                    constexpr int kTail = (kSubBytes - 2 * kPassItems * 16) / 16;
+                    const uint32_t a_t = sub_base + static_cast<uint32_t>(min(fresh_tid() & (kSubLanes - 1), kTail - 1)) * 16u;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq2) : "v"(a_t), "i"(U * kBufBytes + 2 * kPassItems * 16));
+                    check_fold(cq2);
+                }
+                GMPI_STAMP(2);
+            } else {
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g_off) : "v"(a_g));
+            }
+            if (tt + 1 < D && !abl_noissue) issue(Ln, g_off, ic<1 - U>{});
+            GMPI_STAMP(3);
+            const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
+            // tap address constant of this plane and buffer (an integer below 2^24, exact in fp32)
+            const float2 rg = make_float2(__uint_as_float(Gc.x), static_cast<float>(static_cast<int>(Gc.y) + static_cast<int>(tile_base) + U * kBufBytes));
+            if (!abl_nocomp) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    pixel(q, rf, rg);  // (the LDS round trips of the taps are covered by the other waves of the SIMD: 8 are resident)
+                    GMPI_STAMP(5 + q);
+                }
+            }
+            // the records of the next step (the table has D + 2 planes of records per band: no bounds tests)
+            const uint4* __restrict__ rn = myrec + static_cast<int64_t>(tt + 1) * kRecStep;
+            Fc = rn[1], Gc = rn[2], Ln = rn[kRecStep];
+            static_assert(PPT == 2 && kNP <= 3, "pixel slots / check passes");
+        };
+        // (the per-pixel state must sit in registers through the plane loop: a reload there is a vector memory operation on the DMA's counter)
+#pragma unroll
+        for (int q = 0; q < PPT; ++q)
+            asm volatile("" : "+v"(rx[q]), "+v"(ry[q]), "+v"(rz[q]), "+v"(rcp_rz[q]), "+v"(A[q].T), "+v"(A[q].r), "+v"(A[q].g), "+v"(A[q].b), "+v"(A[q].z));
+        if (check_range) {  // zero-fill of the staging buffers (see check_fold)
+            for (int i = tid; i < 2 * kBufBytes / 16; i += kNT) reinterpret_cast<uint4*>(smem + G::kOffBytes)[i] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();  // (also: the loader offsets are in place)
+        issue(myrec[0], reinterpret_cast<const uint32_t*>(smem)[fresh_tid()], ic<0>{});  // plane 0
+        Fc = myrec[1], Gc = myrec[2], Ln = myrec[kRecStep];
+        for (int t = 0; t < D; t += 2) {
+            stage(t, ic<0>{});
+            if (t + 1 < D) stage(t + 1, ic<1>{});
+        }
+        // ---- the verdict of the range check.  -0.0 is a legal value whose pattern sits above that of 1.0: a maximum of exactly that pattern
+        //      says nothing about the values below it, so such a band re-tests its texels one by one (cold: never for generator output) ----
+        if (check_range) {
+            constexpr uint32_t kOne = BF ? 0x3f80u : 0x3f800000u, kNegZero = BF ? 0x8000u : 0x80000000u;
+            const uint32_t mx = BF ? (chk_acc & 0xffffu) : chk_acc;
+#ifdef GMPI_TUNE
+            if (p.status != nullptr && mx > kOne) { atomicMax(p.status + 1, mx); atomicMax(p.status + 2, static_cast<uint32_t>(band_id)); atomicMax(p.status + 3, static_cast<uint32_t>(tid)); }
+#endif
+            if (__any(mx > kOne)) {
+                if (__any(mx > kOne && mx != kNegZero)) bad_w |= 2u;
+                else {
+                    int l_col, l_line, l_row;
+                    bool l_on;
+                    loader_pos(l_col, l_line, l_row, l_on);
+                    const uint32_t g0 = reinterpret_cast<const uint32_t*>(smem)[fresh_tid()];
+                    bool lane_bad = false;
+                    for (int t = 0; t < D; ++t) {
+                        const uint4 rl = myrec[static_cast<int64_t>(t) * kRecStep];
+                        const int dims = static_cast<int>(rl.z), ext = static_cast<int>(rl.w), nq = dims & 0xff, rows = (dims >> 8) & 0xff;
+                        const uint32_t clo = dims < 0 ? (ext & 0xff) : 0u, ncol = dims < 0 ? ((ext >> 8) & 0xff) : static_cast<uint32_t>(nq);
+                        const uint32_t llo = dims < 0 ? 4 * ((ext >> 16) & 0xff) : 0u, nline = dims < 0 ? 4 * ((ext >> 24) & 0xff) : static_cast<uint32_t>(4 * rows);
+                        const unsigned char* org = reinterpret_cast<const unsigned char*>((static_cast<uint64_t>(rl.y) << 32) | rl.x);
+                        for (int r = 0; r < kNP; ++r) {
+                            const bool in = l_on && l_col < nq && (static_cast<uint32_t>(l_col) - clo < ncol) && (static_cast<uint32_t>(l_line + 4 * r * kRPP) - llo < nline);
+                            if (!in) continue;
+                            const uint4 q = *reinterpret_cast<const uint4*>(org + g0 + static_cast<uint32_t>(r) * pass_off);
+                            const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (BF) lane_bad |= !((d[c] & 0xffffu) <= kOne || (d[c] & 0xffffu) == kNegZero) || !((d[c] >> 16) <= kOne || (d[c] >> 16) == kNegZero);
+                                else lane_bad |= !(d[c] <= kOne || d[c] == kNegZero);
+                            }
+                        }
+                    }
+                    if (__any(lane_bad)) bad_w |= 2u;
+                }
+            }
         }
     }
 
@@ -557,7 +580,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
     }
     report_status(p.status, bad);
 #ifdef GMPI_PROF
-    if (p.status != nullptr && band_id == 700 && tid == 320) {  // one wave in the middle of the launch
+    if (p.status != nullptr && band_id == 700 && threadIdx.x == 320) {  // one wave in the middle of the launch
         uint64_t now_;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_));
         for (int i = 0; i < 8; ++i) p.status[8 + i] = prof_acc[i];
@@ -566,17 +589,39 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
 #endif
 }
 
+static void band_grid(const KParams& p, int& bands_x, int& bands_y, int& n_bands) {
+    bands_x = (p.W + NSB * SBW - 1) / (NSB * SBW), bands_y = (p.H + SBH - 1) / SBH;
+    n_bands = bands_x * bands_y * p.N;
+}
+// workspace: [n_bands] header words (padded to 256 bytes), then (n_bands * D + 2) * NSB records of 64 bytes
+static uint64_t ws_hdr_bytes(int n_bands) { return (static_cast<uint64_t>(n_bands) * 4 + 255) / 256 * 256; }
+static uint64_t ws_bytes(const KParams& p) {
+    int bx, by, nb;
+    band_grid(p, bx, by, nb);
+    return ws_hdr_bytes(nb) + (static_cast<uint64_t>(nb) * p.D + 2) * NSB * (kRecU4 * 16);
+}
+
 template <typename TexT>
 static hipError_t launch_t(const KParams& p, hipStream_t stream) {
-    const int bands_x = (p.W + NSB * SBW - 1) / (NSB * SBW), bands_y = (p.H + SBH - 1) / SBH;
-    const int n_bands = bands_x * bands_y * p.N;
+    int bands_x, bands_y, n_bands;
+    band_grid(p, bands_x, bands_y, n_bands);
     const dim3 grid(((n_bands + 7) / 8) * 8), block(kNT);
     const bool acf = p.flags & 1u;
     const float cx = acf ? static_cast<float>(p.Wt - 1) * 0.5f : static_cast<float>(p.Wt), cy = acf ? static_cast<float>(p.Ht - 1) * 0.5f : static_cast<float>(p.Ht);
+    uint32_t* hdr = static_cast<uint32_t*>(p.ws);
+    uint4* recs = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands));
+    // 1. the geometry table (a few microseconds: one thread per band, plane and sub-block)
+    hipError_t e = hipMemsetAsync(hdr, 0, ws_hdr_bytes(n_bands), stream);
+    if (e != hipSuccess) return e;
+    const int64_t total = static_cast<int64_t>(n_bands) * p.D * NSB;
+    const dim3 tgrid(static_cast<unsigned>((total + 255) / 256)), tblock(256);
+    if (acf) hipLaunchKernelGGL((band_table_kernel<TexT, true>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr);
+    else hipLaunchKernelGGL((band_table_kernel<TexT, false>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr);
+    // 2. the render
     const int sel = (p.flags & 1u ? 4 : 0) | (p.flags & (1u << 4) ? 2 : 0) | (p.flags & (1u << 3) ? 1 : 0);  // align_corners, strict order, range check
     switch (sel) {
 #define GMPI_BAND_CASE(I, AC_, ST_, CK_) \
-    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy); break;
+    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr); break;
         GMPI_BAND_CASE(0, false, false, false) GMPI_BAND_CASE(1, false, false, true) GMPI_BAND_CASE(2, false, true, false) GMPI_BAND_CASE(3, false, true, true)
         GMPI_BAND_CASE(4, true, false, false) GMPI_BAND_CASE(5, true, false, true) GMPI_BAND_CASE(6, true, true, false) GMPI_BAND_CASE(7, true, true, true)
 #undef GMPI_BAND_CASE
@@ -586,8 +631,12 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
 
 }  // namespace band
 
+uint64_t band_workspace_bytes(const KParams& p) { return band::ws_bytes(p); }
+
 bool band_variant_supports(const KParams& p, int dtype) {
-    if (dtype == 2) return false;  // fp16 volumes: render_lds.hip (a d16 load yields the half's bits, not an fp32 value)
+    if (dtype == 2) return false;
+    if (p.ws == nullptr || p.ws_bytes < band::ws_bytes(p) || reinterpret_cast<uintptr_t>(p.ws) % 256 != 0) return false;  // needs the caller's workspace
+    if (static_cast<int64_t>(p.N) * p.D * ((p.W + 255) / 256) * ((p.H + 7) / 8) > (int64_t(1) << 28)) return false;  // fp16 volumes: render_lds.hip (a d16 load yields the half's bits, not an fp32 value)
     const int es = dtype == 0 ? 4 : 2, tpi = 16 / es;
     if (p.Wt % tpi != 0) return false;
     if (reinterpret_cast<uintptr_t>(p.rgba) % 16 != 0) return false;

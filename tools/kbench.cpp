@@ -76,6 +76,12 @@ int main(int argc, char** argv) {
     p.struct_size = sizeof p; p.rgba_dtype = dt; p.N = N; p.M = N; p.D = D; p.Ht = p.Wt = p.H = p.W = S; p.views_per_mpi = 1;
     p.rgba = vol; p.rgba_stride[0] = (int64_t)D * plane; p.rgba_stride[1] = plane; p.rgba_stride[2] = chan; p.rgba_stride[3] = S; p.rgba_stride[4] = 1;
     p.dhw = d_dhw; p.ray_dir = d_ray; p.eye_pos = d_eye; p.z_dir = d_zd; p.rgb_out = d_rgb; p.depth_out = d_dep; p.status = d_st;
+    {  // workspace for the kernels that want one (GMPI_VARIANT_BAND)
+        auto wsb = (uint64_t (*)(const GmpiRenderParams*))dlsym(h, "gmpi_render_workspace_bytes");
+        p.flags = GMPI_FLAG_ALIGN_CORNERS;
+        const uint64_t need = wsb ? wsb(&p) : 0;
+        if (need) { CK(hipMalloc(&p.workspace, need)); p.workspace_bytes = need; printf("workspace %.1f MB\n", need / 1e6); }
+    }
     std::vector<float> ref_rgb, ref_dep, rgb(npix * 3), dep(npix);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::string vs = argv[4];
