@@ -48,20 +48,18 @@ template <typename TexT> struct Geo {
     static constexpr int kLineBytes = kCols * 16;
     static constexpr int kRowBytes = 4 * kLineBytes;
     static constexpr int kIPR = 4 * kCols;                  // items per texel row
-    // LDS: every sub-block has kRowSlots texel rows of staging space, used as 2 buffers of kRowSlots / 2 rows (one plane in flight behind the one
-    // being composited) or -- when the band's boxes are no taller than kRowSlots / 3 rows, the usual case for a mildly tilted camera -- as 3
-    // buffers (two planes in flight: a plane step then no longer waits for a full memory round trip).  Chosen per band from the table's header.
-    static constexpr int kRowSlots = kES == 2 ? 30 : 14;
-    static constexpr int kMaxRows = kRowSlots / 2;          // tallest box the staged path takes
-    static constexpr int kAllBufBytes = NSB * kRowSlots * kRowBytes;   // 76800 (bf16)
+    static constexpr int kMaxRows = kES == 2 ? 15 : 7;      // rows per sub-block buffer
+    static constexpr int kCapItems = kMaxRows * kIPR;
+    static constexpr int kSubBytes = kCapItems * 16;        // 9600 (bf16)
+    static constexpr int kBufBytes = NSB * kSubBytes;
     // One DMA pass of a sub-block's lanes moves kRPP whole texel rows (lanes beyond kRPP * kIPR idle): a lane's item of pass r is its item
     // of pass 0 moved down by r * kRPP rows -- one per-lane offset register, the pass in the instruction's scalar offset.
     static constexpr int kRPP = kSubLanes / kIPR;           // 6 (bf16) / 3 (fp32) rows per pass
     static constexpr int kPassItems = kRPP * kIPR;          // 240 active lanes
     static constexpr int kNP = 3;                           // DMA passes per plane at most
-    static_assert((kMaxRows + kRPP - 1) / kRPP <= kNP && (kRowSlots / 3 + kRPP - 1) / kRPP <= 2, "passes");
-    static constexpr int kOffBytes = kNT * 4;               // per-lane loader offsets (parked in LDS: a VGPR through the pixel phase is dearer)
-    static constexpr int kLdsBytes = kOffBytes + kAllBufBytes;
+    static_assert((kMaxRows + kRPP - 1) / kRPP <= kNP, "passes");
+    static constexpr int kOffBytes = kNT * 4;               // per-lane loader offsets (kept in LDS: a VGPR through the plane loop is dearer)
+    static constexpr int kLdsBytes = kOffBytes + 2 * kBufBytes;
 };
 static_assert(Geo<bf16_t>::kLdsBytes * 2 <= 160 * 1024 && Geo<float>::kLdsBytes * 2 <= 160 * 1024, "2 workgroups per CU");
 
@@ -95,13 +93,7 @@ __device__ __forceinline__ void dma16x2(uint32_t voff, uint32_t soff1, const u32
                  : "=&s"(save) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(m0), "s"(m1), "s"(soff1), "i"(D0), "i"(D0 + STEP)
                  : "memory", "scc");
 }
-__device__ __forceinline__ void wait_vmcnt(int n) {  // n is wave-uniform and small
-    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-}
-__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // (a d16_hi load zeroes the low half of its destination on gfx950: tools/ubench/r3_probe.hip `sem`)
 template <int O> __device__ __forceinline__ void tap16(uint32_t& t, uint32_t a) {
     asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(t) : "v"(a), "i"(O));
@@ -133,15 +125,14 @@ __device__ __forceinline__ void band_to_view(const KParams& p, int band_id, int 
 //        uint4 L = box origin address lo, hi | dims | ext        uint4 F = zdiff, w/2, h/2, RN(2/w)        uint4 G = RN(2/h), gpart, -, -
 //      dims = items per line | rows << 8, sign bit set when part of the box lies outside the texture (zeros padding: the loader then takes the
 //      predicated form); ext = the in-texture item columns [clo, clo + ncol) and rows [rlo, rlo + nrow); gpart = sub-block's LDS offset minus
-//      the box origin in LDS bytes (tap address = sub-block's buffer + gpart + iy0 * kRowBytes + ix0 * kES).  hdr[band] = the tallest box of the
-//      band in rows, or kHdrUnfit: some box does not fit the staging buffer -> the band takes the direct gather.
+//      the box origin in LDS bytes (tap address = buffer + gpart + iy0 * kRowBytes + ix0 * kES).  hdr[band] != 0: some box of the band does
+//      not fit its staging buffer -> the band takes the direct gather.
 constexpr int kRecU4 = 4;  // uint4 per record
-constexpr uint32_t kHdrUnfit = 1u << 30;  // header word of a band: the tallest box (rows), or this mark
 template <typename TexT, bool AC>
 __global__ __launch_bounds__(256) void band_table_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
                                                          uint4* __restrict__ recs, uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
-    constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kRowBytes = G::kRowBytes;
+    constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes;
     const int64_t total = static_cast<int64_t>(n_bands) * p.D * NSB;
     const int64_t i0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t i = i0 < total ? i0 : total - 1;  // (surplus threads repeat the last record: the wave reduction below wants every lane)
@@ -193,62 +184,61 @@ __global__ __launch_bounds__(256) void band_table_kernel(const KParams p, const 
     } else {
         qx0 = 0, by0 = 0;
     }
-    {  // tallest box of the band: reduced over the lanes of the wave that belong to the same band, one atomic per band and wave
-        uint32_t v = nq > 0 ? static_cast<uint32_t>(nrows) : kHdrUnfit;
+    {  // unfit mark of the band: reduced over the lanes of the wave that belong to the same band, one atomic per band and wave at most
+       // (thousands of lanes hitting one word serialise: 274 us for a tilted view before, 25 us now)
+        const bool unfit = nq <= 0;
         const int first_band = __builtin_amdgcn_readfirstlane(band_id);
         if (__all(band_id == first_band)) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v = max(v, static_cast<uint32_t>(__shfl_xor(static_cast<int>(v), o)));
-            if ((threadIdx.x & 63) == 0) atomicMax(hdr + band_id, v);
-        } else {
-            atomicMax(hdr + band_id, v);
+            if (__any(unfit) && (threadIdx.x & 63) == 0) atomicOr(hdr + band_id, 1u);
+        } else if (unfit) {
+            atomicOr(hdr + band_id, 1u);
         }
     }
     const uint64_t origin = reinterpret_cast<uint64_t>(vol + (static_cast<int64_t>(k) * p.s_plane + static_cast<int64_t>(by0) * p.s_row + qx0));
-    const int gpart = -(by0 * kRowBytes + qx0 * kES);
+    const int gpart = b * kSubBytes - (by0 * kRowBytes + qx0 * kES);
     uint4* r = recs + i * kRecU4;
     r[0] = make_uint4(static_cast<uint32_t>(origin & 0xffffffffu), static_cast<uint32_t>((origin >> 32) & 0xffffu), static_cast<uint32_t>(dims), static_cast<uint32_t>(ext));
     r[1] = make_uint4(__float_as_uint(zdiff), __float_as_uint(hw), __float_as_uint(hh), __float_as_uint(1.0f / hw));
     r[2] = make_uint4(__float_as_uint(1.0f / hh), static_cast<uint32_t>(gpart), 0u, 0u);
 }
 
-template <typename TexT, bool AC, bool STRICT, bool CHECK, int NBK>
+template <typename TexT, bool AC, bool STRICT, bool CHECK>
 __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
                                                          const uint4* __restrict__ recs, const uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kNP = G::kNP;
-    constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes;
+    constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
     constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
     constexpr bool BF = kES == 2;
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::kLdsBytes];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kOffBytes)));
+    const uint32_t goff_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)smem));
 
     // ---- blockIdx -> band.  XCD x = blockIdx % 8 gets a contiguous run of the bands of EVERY view (group of views that share an MPI): row-major
-    //      neighbours share halo rows in one L2, and a launch that only takes some of the views (the 2- / 3-buffer split) still fills every XCD ----
+    //      neighbours share halo rows in one L2, and the XCDs walk the views together (measured 4 % faster than one run of all bands per XCD,
+    //      where different XCDs read different views at the same time) ----
     const int group_bands = bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1);
     const int per_xcd = (group_bands + 7) / 8;                      // bands of one group per XCD
     const int n_groups = (n_bands + group_bands - 1) / group_bands;
     const int jb = blockIdx.x / 8, grp = jb / per_xcd, rr = jb - grp * per_xcd;
     const int in_group = (blockIdx.x % 8) * per_xcd + rr;
-    const int band_id = grp * group_bands + in_group;
-    if (grp >= n_groups || in_group >= group_bands || band_id >= n_bands) return;
+    int band_id = grp * group_bands + in_group;
+    if (grp >= n_groups || in_group >= group_bands) band_id = n_bands;
+#ifdef GMPI_TUNE  // (experiment: one contiguous run of ALL bands per XCD)
+    if (p.flags & (1u << 19)) band_id = static_cast<int>(blockIdx.x % 8) * ((n_bands + 7) / 8) + static_cast<int>(blockIdx.x / 8);
+#endif
+    if (band_id >= n_bands) return;
     int n, brem;
     band_to_view(p, band_id, bands_x * bands_y, n, brem);
     const int byi = brem / bands_x, bxi = brem - byi * bands_x;
 
     const int tid = threadIdx.x;
-    // Registers are the scarce resource (64 per lane for 8 waves per SIMD): values that only depend on the thread index are recomputed where they
-    // are needed -- from the wave index (a scalar register) and the lane index (v_mbcnt) -- so that not even the thread index lives in a VGPR
-    // through the plane loop.
+    // Registers are the scarce resource (64 per lane for 8 waves per SIMD): values that only depend on the thread index are
+    // recomputed from a laundered copy of it where they are needed, so that they do not live through the plane loop.
+    auto fresh_tid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    auto fresh_tid = [&]() {
-        if (NBK == 3) return wave * 64 + static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-        int t = tid;  // (the 2-buffer instance allocates better with a laundered copy of the thread index: checked by tools/isa_scratch.py)
-        asm volatile("" : "+v"(t));
-        return t;
-    };
     const int sb = wave / WPS, wj = wave % WPS;  // sub-block of this wave, its first pixel row in the sub-block
     const int lane = tid & 63;
     // status bits: kept wave-uniform (a scalar register) until the epilogue -- a per-lane word would cost a VGPR through the plane loop
@@ -298,19 +288,21 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         const int t = fresh_tid() & (kSubLanes - 1);
         l_line = t / kCols, l_col = t - l_line * kCols, l_row = l_line >> 2, l_on = t < kPassItems;
     };
-    {  // byte offset of this lane's pass-0 item from the box origin: parked in LDS, fetched at the end of every plane step for the next one
+    {  // byte offset of this lane's pass-0 item from the box origin: parked in LDS, read back with the per-plane burst
         int l_col, l_line, l_row;
         bool l_on;
         loader_pos(l_col, l_line, l_row, l_on);
         reinterpret_cast<uint32_t*>(smem)[tid] = static_cast<uint32_t>(l_row * s_row + (l_line & 3) * s_chan + kTPI * l_col) * static_cast<uint32_t>(kES);
     }
-    const uint32_t goff_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)smem));
     const uint32_t pass_off = static_cast<uint32_t>(kRPP * s_row) * static_cast<uint32_t>(kES), pass_off2 = 2 * pass_off;           // per pass
+    const uint32_t sub_base = tile_base + static_cast<uint32_t>(sb * kSubBytes);
+    const uint32_t wave_dst = sub_base + static_cast<uint32_t>(wj) * 1024u;  // pass r: + r * kPassItems * 16
 
-    // Ablation switches of the profiling builds (tools/build_tune.sh: no memory traffic / no compositing / no DMA instructions).  The ABI rejects
-    // undefined flag bits (gmpi_abi.hip), so in the shipped library they are always 0 -- but they stay run-time values on purpose: with them folded
-    // to constants hipcc schedules the plane loop differently and spills two registers into it (checked per build by tools/isa_scratch.py).
+#ifdef GMPI_TUNE
     const bool abl_noload = (p.flags & (1u << 16)) != 0, abl_nocomp = (p.flags & (1u << 17)) != 0, abl_noissue = (p.flags & (1u << 18)) != 0;
+#else
+    constexpr bool abl_noload = false, abl_nocomp = false, abl_noissue = false;
+#endif
 
 #ifdef GMPI_PROF  // per-phase shader-clock totals of one wave (status words 8..): barrier | LDS burst | range check | DMA issue | - | pixel 0 | pixel 1
     uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -326,10 +318,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
     const uint4* __restrict__ myrec = recs + (static_cast<int64_t>(band_id) * D * NSB + sb) * kRecU4;
     constexpr int kRecStep = NSB * kRecU4;  // uint4 from plane t to plane t + 1
 
-    const uint32_t band_rows = hdr[band_id];  // tallest box of the band, or the unfit mark
-    // two launches share the bands: the 3-buffer kernel takes those whose boxes fit a third of the row slots, the 2-buffer kernel the others
-    if ((band_rows <= static_cast<uint32_t>(G::kRowSlots / 3)) != (NBK == 3)) return;
-    if (band_rows >= kHdrUnfit) {
+    if (hdr[band_id] != 0) {
         // ---- last resort (a box does not fit: tilted camera, texture much finer than the image, degenerate rays): direct gather, same arithmetic ----
 #pragma unroll
         for (int q = 0; q < PPT; ++q) {
@@ -349,6 +338,57 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         float dots[PPT];
 #pragma unroll
         for (int q = 0; q < PPT; ++q) dots[q] = STRICT ? ray_dot(q) : 0.0f;  // (default mode applies the dot product once, at the end)
+        // ---- per wave: exec masks / pass count of the box of the plane last issued (recomputed when the box shape changes: a handful of
+        //      times per band).  The range check of plane t runs BEFORE plane t + 1 is issued, so it sees plane t's masks. ----
+        uint64_t m_cur[kNP];
+        int dims_cur = 0;
+        bool three = false;  // the box of the plane last issued needs the third pass
+#pragma unroll
+        for (int r = 0; r < kNP; ++r) m_cur[r] = 0;
+
+        auto issue = [&](const uint4& rl, uint32_t g_off, auto ub) {  // DMA of the plane with record part L = rl into buffer U (this wave's part of its sub-block's box)
+            constexpr int U = decltype(ub)::value;
+            const int dims = static_cast<int>(rl.z);
+            const u32x4 rsrc = {rl.x, rl.y, 0x80000000u, 0x00020000u};  // raw buffer, num_records 2^31: only the explicit offset below is rejected
+            if (dims >= 0) {  // the box lies inside the texture: lanes of the box load, the others are switched off
+                if (dims != dims_cur) {
+                    const int nq = dims & 0xff, rows = dims >> 8;
+                    dims_cur = dims;
+                    three = rows > 2 * kRPP;
+                    int l_col, l_line, l_row;
+                    bool l_on;
+                    loader_pos(l_col, l_line, l_row, l_on);
+#pragma unroll
+                    for (int r = 0; r < kNP; ++r) {
+                        m_cur[r] = __ballot(l_on && l_col < nq && l_row + r * kRPP < rows);
+                        if (abl_noload) m_cur[r] = 0;
+                    }
+                }
+                static_assert(kNP == 3, "dma16x3");
+                if (three) dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
+                else dma16x2<U * kBufBytes, kPassItems * 16>(g_off, pass_off, rsrc, wave_dst, m_cur[0], m_cur[1]);
+            } else {  // zeros padding: every lane of the box rows is active, lanes outside the texture get the out-of-range offset
+                const int ext = static_cast<int>(rl.w);
+                const int rows = (dims >> 8) & 0xff;
+                const uint32_t clo = ext & 0xff, ncol = (ext >> 8) & 0xff, llo = 4 * ((ext >> 16) & 0xff), nline = 4 * ((ext >> 24) & 0xff);
+                dims_cur = dims;
+                three = rows > 2 * kRPP;
+                const int npk = (rows + kRPP - 1) / kRPP;
+                int l_col, l_line, l_row;
+                bool l_on;
+                loader_pos(l_col, l_line, l_row, l_on);
+#pragma unroll
+                for (int r = 0; r < kNP; ++r) {
+                    m_cur[r] = __ballot(l_on && l_row + r * kRPP < rows);
+                    if (abl_noload) m_cur[r] = 0;
+                    if (r < npk) {
+                        const bool ok = (static_cast<uint32_t>(l_col) - clo < ncol) & (static_cast<uint32_t>(l_line + 4 * r * kRPP) - llo < nline);
+                        dma16(ok ? g_off : 0x80000000u, r * pass_off, rsrc, wave_dst + static_cast<uint32_t>(U * kBufBytes + r * (kPassItems * 16)), m_cur[r]);
+                    }
+                }
+            }
+        };
+
         // ---- [0,1] test of the landed items (mpi.py:185-187).  Every loader lane reads its own items back and folds their bit patterns into a
         //      running unsigned maximum (non-negative floats order like unsigned integers: in [0,1] <=> pattern <= that of 1.0; the sign bit and
         //      NaN / Inf compare above): 4 (bf16) / 2 (fp32) instructions per 16-byte item, no compare, no branch in the plane loop.  The staging
@@ -427,148 +467,85 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         };
 
 
-
-        // ---- the staged path, for NB = 2 or 3 staging buffers per sub-block (NB - 1 planes in flight behind the one being composited) ----
-        auto run = [&](auto nbc) {
-            constexpr int NB = decltype(nbc)::value;
-            constexpr int kBufRows = G::kRowSlots / NB;                 // rows per buffer: 15 | 10 (bf16)
-            constexpr int kSubBytes = kBufRows * kRowBytes;             // one sub-block's buffer
-            constexpr int kBufBytes = NSB * kSubBytes;                  // one buffer of the band
-            constexpr bool kThird = kBufRows > 2 * kRPP;                // can a box have a third DMA pass?
-            const uint32_t sub_base = tile_base + static_cast<uint32_t>(sb * kSubBytes);
-            const uint32_t wave_dst = sub_base + static_cast<uint32_t>(wj) * 1024u;  // pass r: + r * kPassItems * 16
-            // per wave: exec masks of the box shape last issued (recomputed when the shape changes: a handful of times per band)
-            uint64_t m_cur[kNP];
-            int dims_cur = 0;
-            bool three = false;  // the box of the plane last issued has a third pass
-#pragma unroll
-            for (int r = 0; r < kNP; ++r) m_cur[r] = 0;
-
-            // DMA of the plane with record part L = rl into buffer U (this wave's part of its sub-block's box); returns the DMA instructions issued
-            auto issue = [&](const uint4& rl, uint32_t g_off, auto ub) -> int {
-                constexpr int U = decltype(ub)::value;
-                const int dims = static_cast<int>(rl.z);
-                const u32x4 rsrc = {rl.x, rl.y, 0x80000000u, 0x00020000u};  // raw buffer, num_records 2^31: only the explicit offset below is rejected
-                if (dims >= 0) {  // the box lies inside the texture: lanes of the box load, the others are switched off
-                    if (dims != dims_cur) {
-                        const int nq = dims & 0xff, rows = dims >> 8;
-                        dims_cur = dims;
-                        three = kThird && rows > 2 * kRPP;
-                        int l_col, l_line, l_row;
-                        bool l_on;
-                        loader_pos(l_col, l_line, l_row, l_on);
-#pragma unroll
-                        for (int r = 0; r < kNP; ++r) {
-                            m_cur[r] = __ballot(l_on && l_col < nq && l_row + r * kRPP < rows);
-                            if (abl_noload) m_cur[r] = 0;
-                        }
-                    }
-                    if (kThird && three) {
-                        dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
-                        return 3;
-                    }
-                    dma16x2<U * kBufBytes, kPassItems * 16>(g_off, pass_off, rsrc, wave_dst, m_cur[0], m_cur[1]);
-                    return 2;
+        // One plane step.  The records come through scalar loads issued a step ahead (part L of plane t + 2 for the DMA of the next step,
+        // parts F, G of plane t + 1 for its pixels); this lane's items of the current plane (range check) and its loader offset come in one
+        // LDS burst behind the barrier.
+        uint4 Ln, Fc, Gc;  // wave-uniform: scalar registers
+        auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
+            constexpr int U = decltype(ub)::value;
+            wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
+            GMPI_STAMP(0);
+            const uint32_t a_it = sub_base + static_cast<uint32_t>(fresh_tid() & (kSubLanes - 1)) * 16u;
+            const uint32_t a_g = goff_base + (static_cast<uint32_t>(fresh_tid()) << 2);
+            // (loads and their wait in ONE statement: the compiler may copy an asm load's destination as soon as the statement ends)
+            u32x4 cq0, cq1, cq2;
+            uint32_t g_off;
+            const bool three_cur = three;  // set by the issue of this plane, one step ago
+#ifdef GMPI_BAND_ISSUE_FIRST
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g_off) : "v"(a_g));
+            if (tt + 1 < D && !abl_noissue) issue(Ln, g_off, ic<1 - U>{});
+            GMPI_STAMP(3);
+            if (check_range) {
+                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                check_fold(cq0), check_fold(cq1);
+                if (three_cur) {
+                    constexpr int kTail = (kSubBytes - 2 * kPassItems * 16) / 16;
+                    const uint32_t a_t = sub_base + static_cast<uint32_t>(min(fresh_tid() & (kSubLanes - 1), kTail - 1)) * 16u;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq2) : "v"(a_t), "i"(U * kBufBytes + 2 * kPassItems * 16));
+                    check_fold(cq2);
                 }
-                // zeros padding: every lane of the box rows is active, lanes outside the texture get the out-of-range offset
-                const int ext = static_cast<int>(rl.w);
-                const int rows = (dims >> 8) & 0xff;
-                const uint32_t clo = ext & 0xff, ncol = (ext >> 8) & 0xff, llo = 4 * ((ext >> 16) & 0xff), nline = 4 * ((ext >> 24) & 0xff);
-                dims_cur = dims;
-                three = kThird && rows > 2 * kRPP;
-                const int npk = (rows + kRPP - 1) / kRPP;
-                int l_col, l_line, l_row;
-                bool l_on;
-                loader_pos(l_col, l_line, l_row, l_on);
-#pragma unroll
-                for (int r = 0; r < kNP; ++r) {
-                    m_cur[r] = __ballot(l_on && l_row + r * kRPP < rows);
-                    if (abl_noload) m_cur[r] = 0;
-                    if (r < npk) {
-                        const bool ok = (static_cast<uint32_t>(l_col) - clo < ncol) & (static_cast<uint32_t>(l_line + 4 * r * kRPP) - llo < nline);
-                        dma16(ok ? g_off : 0x80000000u, r * pass_off, rsrc, wave_dst + static_cast<uint32_t>(U * kBufBytes + r * (kPassItems * 16)), m_cur[r]);
-                    }
-                }
-                return npk;
-            };
-
-            // One plane step.  The records come through scalar loads issued a step ahead (part L of the plane the NEXT step will issue, parts F, G
-            // of the next plane's pixels); the lane's loader offset is re-read from LDS behind the pixels.
-            uint4 Ln, Fc, Gc;  // wave-uniform: scalar registers
-            uint32_t g_next;   // this lane's loader offset (lives across the barrier only)
-            int newer = 0;     // DMA instructions of the planes in flight behind the one the next step composites (NB = 3)
-            auto fetch_goff = [&]() {
-                const uint32_t a_g = goff_base + (static_cast<uint32_t>(fresh_tid()) << 2);
-                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g_next) : "v"(a_g));
-            };
-            auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
-                constexpr int U = decltype(ub)::value;
-                // own DMA of plane tt has landed (those of the planes behind it may stay in flight) -> everybody's has; everybody is done reading plane tt - 1
-                if (NB == 2) wait_vmcnt(0);
-                else wait_vmcnt(tt + 1 < D ? newer : 0);
-                wg_barrier();
-                GMPI_STAMP(0);
-                // the DMA of plane tt + NB - 1 first: its latency is what a plane step may have to wait for
-                const bool three_cur = three;  // (NB = 2: set by the issue of THIS plane, one step ago; issue() moves it on)
-                int cnt = 0;
-                if (tt + NB - 1 < D && !abl_noissue) cnt = issue(Ln, g_next, ic<(U + NB - 1) % NB>{});
-                newer = cnt;
-                GMPI_STAMP(3);
-                if (check_range) {
-                    // (lanes beyond a pass's share of the sub-block's buffer re-read its first item; loads and their wait in ONE statement: the
-                    //  compiler may copy an asm load's destination as soon as the statement ends)
-                    const int slc = fresh_tid() & (kSubLanes - 1);
-                    constexpr int kLim1 = (kSubBytes - kPassItems * 16) / 16, kLim2 = kThird ? (kSubBytes - 2 * kPassItems * 16) / 16 : 1;
-                    const uint32_t a_it = sub_base + static_cast<uint32_t>(slc) * 16u;
-                    const uint32_t a_i1 = kLim1 >= kSubLanes ? a_it : sub_base + static_cast<uint32_t>(min(slc, kLim1 - 1)) * 16u;
-                    u32x4 cq0, cq1, cq2;
-                    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%5\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "v"(a_i1), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                    GMPI_STAMP(1);
-                    check_fold(cq0), check_fold(cq1);
-                    if (kThird && three_cur) {  // (the box of THIS plane has a third pass)
-                        const uint32_t a_t = sub_base + static_cast<uint32_t>(min(slc, kLim2 - 1)) * 16u;
-                        asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq2) : "v"(a_t), "i"(U * kBufBytes + 2 * kPassItems * 16));
-                        check_fold(cq2);
-                    }
-                    GMPI_STAMP(2);
-                }
-                const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
-                // tap address constant of this plane, buffer and sub-block (an integer below 2^24, exact in fp32)
-                const float2 rg = make_float2(__uint_as_float(Gc.x), static_cast<float>(static_cast<int>(Gc.y) + static_cast<int>(sub_base) + U * kBufBytes));
-                if (!abl_nocomp) {
-#pragma unroll
-                    for (int q = 0; q < PPT; ++q) {
-                        pixel(q, rf, rg);  // (the LDS round trips of the taps are covered by the other waves of the SIMD: 8 are resident)
-                        GMPI_STAMP(5 + q);
-                    }
-                }
-                // the records of the next step (the table is padded by three planes of records: no bounds tests)
-                const uint4* __restrict__ rn = myrec + static_cast<int64_t>(tt + 1) * kRecStep;
-                Fc = rn[1], Gc = rn[2], Ln = rn[(NB - 1) * kRecStep];
-                fetch_goff();
-                static_assert(PPT == 2 && kNP <= 3, "pixel slots / check passes");
-            };
-            fetch_goff();
-            issue(myrec[0], g_next, ic<0>{});  // plane 0
-            if (NB == 3 && D > 1) newer = issue(myrec[kRecStep], g_next, ic<1>{});  // plane 1
-            Fc = myrec[1], Gc = myrec[2], Ln = myrec[(NB - 1) * kRecStep];
-            for (int t = 0; t < D; t += NB) {
-                stage(t, ic<0>{});
-                if (t + 1 < D) stage(t + 1, ic<1>{});
-                if (NB == 3 && t + 2 < D) stage(t + 2, ic<(NB == 3 ? 2 : 0)>{});
+                GMPI_STAMP(2);
             }
+#else
+            if (check_range) {
+                asm volatile("ds_read_b32 %2, %4\n\tds_read_b128 %0, %3 offset:%5\n\tds_read_b128 %1, %3 offset:%6\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(cq0), "=&v"(cq1), "=&v"(g_off)
+                             : "v"(a_it), "v"(a_g), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                GMPI_STAMP(1);
+                check_fold(cq0), check_fold(cq1);
+                if (three_cur) {  // (the box of THIS plane has a third pass: the rest of the sub-block's buffer -- lanes beyond it re-read its first item)
+                    constexpr int kTail = (kSubBytes - 2 * kPassItems * 16) / 16;
+                    const uint32_t a_t = sub_base + static_cast<uint32_t>(min(fresh_tid() & (kSubLanes - 1), kTail - 1)) * 16u;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq2) : "v"(a_t), "i"(U * kBufBytes + 2 * kPassItems * 16));
+                    check_fold(cq2);
+                }
+                GMPI_STAMP(2);
+            } else {
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g_off) : "v"(a_g));
+            }
+            if (tt + 1 < D && !abl_noissue) issue(Ln, g_off, ic<1 - U>{});
+            GMPI_STAMP(3);
+#endif
+            const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
+            // tap address constant of this plane and buffer (an integer below 2^24, exact in fp32)
+            const float2 rg = make_float2(__uint_as_float(Gc.x), static_cast<float>(static_cast<int>(Gc.y) + static_cast<int>(tile_base) + U * kBufBytes));
+            if (!abl_nocomp) {
+#pragma unroll
+                for (int q = 0; q < PPT; ++q) {
+                    pixel(q, rf, rg);  // (the LDS round trips of the taps are covered by the other waves of the SIMD: 8 are resident)
+                    GMPI_STAMP(5 + q);
+                }
+            }
+            // the records of the next step (the table has D + 2 planes of records per band: no bounds tests)
+            const uint4* __restrict__ rn = myrec + static_cast<int64_t>(tt + 1) * kRecStep;
+            Fc = rn[1], Gc = rn[2], Ln = rn[kRecStep];
+            static_assert(PPT == 2 && kNP <= 3, "pixel slots / check passes");
         };
-
         // (the per-pixel state must sit in registers through the plane loop: a reload there is a vector memory operation on the DMA's counter)
 #pragma unroll
         for (int q = 0; q < PPT; ++q)
             asm volatile("" : "+v"(rx[q]), "+v"(ry[q]), "+v"(rz[q]), "+v"(rcp_rz[q]), "+v"(A[q].T), "+v"(A[q].r), "+v"(A[q].g), "+v"(A[q].b), "+v"(A[q].z));
         if (check_range) {  // zero-fill of the staging buffers (see check_fold)
-            for (int i = tid; i < G::kAllBufBytes / 16; i += kNT) reinterpret_cast<uint4*>(smem + G::kOffBytes)[i] = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < 2 * kBufBytes / 16; i += kNT) reinterpret_cast<uint4*>(smem + G::kOffBytes)[i] = make_uint4(0, 0, 0, 0);
         }
-        __syncthreads();
-        run(ic<NBK>{});
+        __syncthreads();  // (also: the loader offsets are in place)
+        issue(myrec[0], reinterpret_cast<const uint32_t*>(smem)[fresh_tid()], ic<0>{});  // plane 0
+        Fc = myrec[1], Gc = myrec[2], Ln = myrec[kRecStep];
+        for (int t = 0; t < D; t += 2) {
+            stage(t, ic<0>{});
+            if (t + 1 < D) stage(t + 1, ic<1>{});
+        }
         // ---- the verdict of the range check.  -0.0 is a legal value whose pattern sits above that of 1.0: a maximum of exactly that pattern
         //      says nothing about the values below it, so such a band re-tests its texels one by one (cold: never for generator output) ----
         if (check_range) {
@@ -653,12 +630,12 @@ static void band_grid(const KParams& p, int& bands_x, int& bands_y, int& n_bands
     bands_x = (p.W + NSB * SBW - 1) / (NSB * SBW), bands_y = (p.H + SBH - 1) / SBH;
     n_bands = bands_x * bands_y * p.N;
 }
-// workspace: [n_bands] header words (padded to 256 bytes), then (n_bands * D + 3) * NSB records of 64 bytes
+// workspace: [n_bands] header words (padded to 256 bytes), then (n_bands * D + 2) * NSB records of 64 bytes
 static uint64_t ws_hdr_bytes(int n_bands) { return (static_cast<uint64_t>(n_bands) * 4 + 255) / 256 * 256; }
 static uint64_t ws_bytes(const KParams& p) {
     int bx, by, nb;
     band_grid(p, bx, by, nb);
-    return ws_hdr_bytes(nb) + (static_cast<uint64_t>(nb) * p.D + 3) * NSB * (kRecU4 * 16);
+    return ws_hdr_bytes(nb) + (static_cast<uint64_t>(nb) * p.D + 2) * NSB * (kRecU4 * 16);
 }
 
 template <typename TexT>
@@ -682,8 +659,7 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
     const int sel = (p.flags & 1u ? 4 : 0) | (p.flags & (1u << 4) ? 2 : 0) | (p.flags & (1u << 3) ? 1 : 0);  // align_corners, strict order, range check
     switch (sel) {
 #define GMPI_BAND_CASE(I, AC_, ST_, CK_) \
-    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_, 3>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr); \
-            hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_, 2>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr); break;
+    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr); break;
         GMPI_BAND_CASE(0, false, false, false) GMPI_BAND_CASE(1, false, false, true) GMPI_BAND_CASE(2, false, true, false) GMPI_BAND_CASE(3, false, true, true)
         GMPI_BAND_CASE(4, true, false, false) GMPI_BAND_CASE(5, true, false, true) GMPI_BAND_CASE(6, true, true, false) GMPI_BAND_CASE(7, true, true, true)
 #undef GMPI_BAND_CASE
@@ -712,7 +688,7 @@ bool band_variant_supports(const KParams& p, int dtype) {
 hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
 #ifdef GMPI_TUNE  // profiling builds: tune bits 8-9 = ablations (no memory traffic / no compositing)
-    p.flags |= static_cast<uint32_t>((tune >> 8) & 7) << 16;
+    p.flags |= static_cast<uint32_t>((tune >> 8) & 15) << 16;
 #else
     (void)tune;
 #endif
