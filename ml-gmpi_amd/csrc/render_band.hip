@@ -22,6 +22,8 @@
 
 #include <type_traits>
 
+#define GMPI_BAND_ISSUE_FIRST 1
+
 namespace gmpi {
 namespace band {
 
@@ -120,91 +122,103 @@ __device__ __forceinline__ void band_to_view(const KParams& p, int band_id, int 
     }
 }
 
-// ---- the geometry table: one 64-byte record per (band, plane, sub-block), written by a small kernel in front of the render kernel and read
-//      by the render kernel's waves through scalar loads (no LDS table, no table builds between the planes, no v_readfirstlane):
-//        uint4 L = box origin address lo, hi | dims | ext        uint4 F = zdiff, w/2, h/2, RN(2/w)        uint4 G = RN(2/h), gpart, -, -
-//      dims = items per line | rows << 8, sign bit set when part of the box lies outside the texture (zeros padding: the loader then takes the
-//      predicated form); ext = the in-texture item columns [clo, clo + ncol) and rows [rlo, rlo + nrow); gpart = sub-block's LDS offset minus
-//      the box origin in LDS bytes (tap address = buffer + gpart + iy0 * kRowBytes + ix0 * kES).  hdr[band] != 0: some box of the band does
-//      not fit its staging buffer -> the band takes the direct gather.
-constexpr int kRecU4 = 4;  // uint4 per record
+// ---- the geometry table, written by a small kernel in front of the render kernel and read by the render kernel's waves through scalar loads
+//      (no LDS table, no table builds between the planes, no v_readfirstlane):
+//        recs[(band * D + plane) * NSB + sub-block] = uint4 { box origin address lo, hi | shape | gpart }          16 bytes
+//        pl[(view * D + plane) * 2] = uint4 { zdiff, w/2, h/2, RN(2/w) }, uint4 { RN(2/h), -, -, - }               32 bytes per view and plane
+//      shape = items per line (bits 0-4) | rows (5-8), and -- only when part of the box lies outside the texture (zeros padding: the loader
+//      then takes the predicated form), marked by the sign bit -- the in-texture item columns [clo, clo + ncol) (bits 9-13, 14-18) and rows
+//      [rlo, rlo + nrow) (19-22, 23-26); gpart = sub-block's LDS offset minus the box origin in LDS bytes (tap address = buffer + gpart +
+//      iy0 * kRowBytes + ix0 * kES).  hdr[band] != 0: some box of the band does not fit its staging buffer -> the band takes the direct gather.
+//      One workgroup per band: the header word is a workgroup reduction (no atomics, nothing to clear).  12.6 MB for BASELINE config 3.
+constexpr int kPlU4 = 2;   // uint4 per (view, plane) record
+__device__ __forceinline__ uint32_t shape_pack(int nq, int rows, int clo, int ncol, int rlo, int nrow, bool inside) {
+    return inside ? static_cast<uint32_t>(nq | rows << 5)
+                  : static_cast<uint32_t>(nq | rows << 5 | clo << 9 | ncol << 14 | rlo << 19 | nrow << 23) | 0x80000000u;
+}
+struct Shape { int nq, rows; uint32_t clo, ncol, rlo, nrow; };
+__device__ __forceinline__ Shape shape_unpack(uint32_t w) {
+    Shape h;
+    h.nq = w & 31, h.rows = (w >> 5) & 15;
+    const bool padded = (w >> 31) != 0;
+    h.clo = padded ? (w >> 9) & 31 : 0u, h.ncol = padded ? (w >> 14) & 31 : static_cast<uint32_t>(h.nq);
+    h.rlo = padded ? (w >> 19) & 15 : 0u, h.nrow = padded ? (w >> 23) & 15 : static_cast<uint32_t>(h.rows);
+    return h;
+}
 template <typename TexT, bool AC>
 __global__ __launch_bounds__(256) void band_table_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
-                                                         uint4* __restrict__ recs, uint32_t* __restrict__ hdr) {
+                                                         uint4* __restrict__ recs, uint4* __restrict__ pl, uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes;
-    const int64_t total = static_cast<int64_t>(n_bands) * p.D * NSB;
-    const int64_t i0 = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    const int64_t i = i0 < total ? i0 : total - 1;  // (surplus threads repeat the last record: the wave reduction below wants every lane)
-    const int b = static_cast<int>(i % NSB), k = static_cast<int>((i / NSB) % p.D), band_id = static_cast<int>(i / (static_cast<int64_t>(NSB) * p.D));
+    static_assert(kCols < 32 && kMaxRows < 16, "shape_pack");
+    const int band_id = blockIdx.x;
     int n, brem;
     band_to_view(p, band_id, bands_x * bands_y, n, brem);
     const int byi = brem / bands_x, bxi = brem - byi * bands_x;
     uint32_t ignore = 0;
     const int m = view_mpi(p, n, ignore);
     const int Ht = p.Ht, Wt = p.Wt, H = p.H, W = p.W;
-    const float* __restrict__ dhw = p.dhw + (static_cast<int64_t>(m) * p.D + k) * 3;
     const float ex = p.eye_pos[3 * n + 0], ey = p.eye_pos[3 * n + 1], ez = p.eye_pos[3 * n + 2];
     const int64_t HW = static_cast<int64_t>(H) * W;
     const float* __restrict__ rdv = p.ray_dir + static_cast<int64_t>(n) * 3 * HW;
     const TexT* __restrict__ vol = static_cast<const TexT*>(p.rgba) + static_cast<int64_t>(m) * p.s_mpi;
-    const float d = dhw[0], ph = dhw[1], pw = dhw[2];
-    const float zdiff = d - ez;
-    const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
     const int sx0 = min(bxi * (NSB * SBW), W - 1), sy0 = byi * SBH;
-    const int bx0p = min(sx0 + b * SBW, W - 1), bx1p = min(sx0 + b * SBW + SBW - 1, W - 1);
     const int by0p = min(sy0, H - 1), by1p = min(sy0 + SBH - 1, H - 1);
-    float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
-    bool finite = true;
+    bool unfit = false;
+    for (int i = threadIdx.x; i < p.D * NSB; i += blockDim.x) {
+        const int b = i % NSB, k = i / NSB;
+        const float* __restrict__ dhw = p.dhw + (static_cast<int64_t>(m) * p.D + k) * 3;
+        const float d = dhw[0], ph = dhw[1], pw = dhw[2];
+        const float zdiff = d - ez;
+        const float hw = pw * 0.5f, hh = ph * 0.5f;  // exact halves: (2x)/w == x/(w/2)
+        const int bx0p = min(sx0 + b * SBW, W - 1), bx1p = min(sx0 + b * SBW + SBW - 1, W - 1);
+        float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
+        bool finite = true;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {  // the warp is a homography: the box of the sub-block's taps is spanned by its 4 corner pixels
-        const int64_t q = static_cast<int64_t>((c & 2) ? by1p : by0p) * W + ((c & 1) ? bx1p : bx0p);
-        float ix, iy, sc, u, v;
-        plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, sc, u, v);
-        finite = finite && (fabsf(ix) < kCoordLimit) && (fabsf(iy) < kCoordLimit);  // false for NaN too
-        mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
-    }
-    int qx0 = 0, by0 = 0, nq = -1, nrows = 0;
-    if (finite) {
-        const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
-        by0 = static_cast<int>(floorf(mny - kBoxEps));
-        const int by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
-        qx0 = bx0 & ~(kTPI - 1);
-        nq = (bx1 - qx0) / kTPI + 1;
-        nrows = by1 - by0 + 1;
-        if (nq > kCols || nrows > kMaxRows) nq = -1;
-    }
-    int dims = 0, ext = 0;
-    if (nq > 0) {  // (qx0 and Wt are multiples of the item width)
-        const int clo = min(max(-qx0 / kTPI, 0), nq), chi = min(max((Wt - qx0) / kTPI, 0), nq);
-        const int rlo = min(max(-by0, 0), nrows), rhi = min(max(Ht - by0, 0), nrows);
-        const bool inside = clo == 0 && chi == nq && rlo == 0 && rhi == nrows;
-        dims = nq | nrows << 8 | (inside ? 0 : static_cast<int>(0x80000000u));
-        ext = clo | (chi - clo) << 8 | rlo << 16 | (rhi - rlo) << 24;
-    } else {
-        qx0 = 0, by0 = 0;
-    }
-    {  // unfit mark of the band: reduced over the lanes of the wave that belong to the same band, one atomic per band and wave at most
-       // (thousands of lanes hitting one word serialise: 274 us for a tilted view before, 25 us now)
-        const bool unfit = nq <= 0;
-        const int first_band = __builtin_amdgcn_readfirstlane(band_id);
-        if (__all(band_id == first_band)) {
-            if (__any(unfit) && (threadIdx.x & 63) == 0) atomicOr(hdr + band_id, 1u);
-        } else if (unfit) {
-            atomicOr(hdr + band_id, 1u);
+        for (int c = 0; c < 4; ++c) {  // the warp is a homography: the box of the sub-block's taps is spanned by its 4 corner pixels
+            const int64_t q = static_cast<int64_t>((c & 2) ? by1p : by0p) * W + ((c & 1) ? bx1p : bx0p);
+            float ix, iy, sc, u, v;
+            plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, sc, u, v);
+            finite = finite && (fabsf(ix) < kCoordLimit) && (fabsf(iy) < kCoordLimit);  // false for NaN too
+            mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
+        }
+        int qx0 = 0, by0 = 0, nq = -1, nrows = 0;
+        if (finite) {
+            const int bx0 = static_cast<int>(floorf(mnx - kBoxEps)), bx1 = static_cast<int>(floorf(mxx + kBoxEps)) + 1;
+            by0 = static_cast<int>(floorf(mny - kBoxEps));
+            const int by1 = static_cast<int>(floorf(mxy + kBoxEps)) + 1;
+            qx0 = bx0 & ~(kTPI - 1);
+            nq = (bx1 - qx0) / kTPI + 1;
+            nrows = by1 - by0 + 1;
+            if (nq > kCols || nrows > kMaxRows) nq = -1;
+        }
+        uint32_t shape = 0;
+        if (nq > 0) {  // (qx0 and Wt are multiples of the item width)
+            const int clo = min(max(-qx0 / kTPI, 0), nq), chi = min(max((Wt - qx0) / kTPI, 0), nq);
+            const int rlo = min(max(-by0, 0), nrows), rhi = min(max(Ht - by0, 0), nrows);
+            const bool inside = clo == 0 && chi == nq && rlo == 0 && rhi == nrows;
+            shape = shape_pack(nq, nrows, clo, chi - clo, rlo, rhi - rlo, inside);
+        } else {
+            qx0 = 0, by0 = 0;
+            unfit = true;
+        }
+        const uint64_t origin = reinterpret_cast<uint64_t>(vol + (static_cast<int64_t>(k) * p.s_plane + static_cast<int64_t>(by0) * p.s_row + qx0));
+        const int gpart = b * kSubBytes - (by0 * kRowBytes + qx0 * kES);
+        recs[(static_cast<int64_t>(band_id) * p.D + k) * NSB + b] =
+            make_uint4(static_cast<uint32_t>(origin & 0xffffffffu), static_cast<uint32_t>((origin >> 32) & 0xffffu), shape, static_cast<uint32_t>(gpart));
+        if (brem == 0 && b == 0) {  // the view's plane constants, once per view
+            uint4* r = pl + (static_cast<int64_t>(n) * p.D + k) * kPlU4;
+            r[0] = make_uint4(__float_as_uint(zdiff), __float_as_uint(hw), __float_as_uint(hh), __float_as_uint(1.0f / hw));
+            r[1] = make_uint4(__float_as_uint(1.0f / hh), 0u, 0u, 0u);
         }
     }
-    const uint64_t origin = reinterpret_cast<uint64_t>(vol + (static_cast<int64_t>(k) * p.s_plane + static_cast<int64_t>(by0) * p.s_row + qx0));
-    const int gpart = b * kSubBytes - (by0 * kRowBytes + qx0 * kES);
-    uint4* r = recs + i * kRecU4;
-    r[0] = make_uint4(static_cast<uint32_t>(origin & 0xffffffffu), static_cast<uint32_t>((origin >> 32) & 0xffffu), static_cast<uint32_t>(dims), static_cast<uint32_t>(ext));
-    r[1] = make_uint4(__float_as_uint(zdiff), __float_as_uint(hw), __float_as_uint(hh), __float_as_uint(1.0f / hw));
-    r[2] = make_uint4(__float_as_uint(1.0f / hh), static_cast<uint32_t>(gpart), 0u, 0u);
+    const int any_unfit = __syncthreads_or(unfit ? 1 : 0);
+    if (threadIdx.x == 0) hdr[band_id] = static_cast<uint32_t>(any_unfit);
 }
 
 template <typename TexT, bool AC, bool STRICT, bool CHECK>
 __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
-                                                         const uint4* __restrict__ recs, const uint32_t* __restrict__ hdr) {
+                                                         const uint4* __restrict__ recs, const uint4* __restrict__ pl, const uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kNP = G::kNP;
     constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
@@ -314,9 +328,10 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
 #define GMPI_STAMP(i) do { } while (0)
 #endif
 
-    // this wave's records: recs[((band * D + t) * NSB + sb) * 4 + part]
-    const uint4* __restrict__ myrec = recs + (static_cast<int64_t>(band_id) * D * NSB + sb) * kRecU4;
-    constexpr int kRecStep = NSB * kRecU4;  // uint4 from plane t to plane t + 1
+    // this wave's records: recs[(band * D + t) * NSB + sb], pl[(n * D + t) * 2 + part]
+    const uint4* __restrict__ myrec = recs + (static_cast<int64_t>(band_id) * D * NSB + sb);
+    const uint4* __restrict__ mypl = pl + static_cast<int64_t>(n) * D * kPlU4;
+    constexpr int kRecStep = NSB;  // uint4 from plane t to plane t + 1
 
     if (hdr[band_id] != 0) {
         // ---- last resort (a box does not fit: tilted camera, texture much finer than the image, degenerate rays): direct gather, same arithmetic ----
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
             const u32x4 rsrc = {rl.x, rl.y, 0x80000000u, 0x00020000u};  // raw buffer, num_records 2^31: only the explicit offset below is rejected
             if (dims >= 0) {  // the box lies inside the texture: lanes of the box load, the others are switched off
                 if (dims != dims_cur) {
-                    const int nq = dims & 0xff, rows = dims >> 8;
+                    const int nq = dims & 31, rows = dims >> 5;
                     dims_cur = dims;
                     three = rows > 2 * kRPP;
                     int l_col, l_line, l_row;
@@ -368,9 +383,9 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                 if (three) dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
                 else dma16x2<U * kBufBytes, kPassItems * 16>(g_off, pass_off, rsrc, wave_dst, m_cur[0], m_cur[1]);
             } else {  // zeros padding: every lane of the box rows is active, lanes outside the texture get the out-of-range offset
-                const int ext = static_cast<int>(rl.w);
-                const int rows = (dims >> 8) & 0xff;
-                const uint32_t clo = ext & 0xff, ncol = (ext >> 8) & 0xff, llo = 4 * ((ext >> 16) & 0xff), nline = 4 * ((ext >> 24) & 0xff);
+                const Shape h = shape_unpack(static_cast<uint32_t>(dims));
+                const int rows = h.rows;
+                const uint32_t clo = h.clo, ncol = h.ncol, llo = 4 * h.rlo, nline = 4 * h.nrow;
                 dims_cur = dims;
                 three = rows > 2 * kRPP;
                 const int npk = (rows + kRPP - 1) / kRPP;
@@ -470,7 +485,8 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         // One plane step.  The records come through scalar loads issued a step ahead (part L of plane t + 2 for the DMA of the next step,
         // parts F, G of plane t + 1 for its pixels); this lane's items of the current plane (range check) and its loader offset come in one
         // LDS burst behind the barrier.
-        uint4 Ln, Fc, Gc;  // wave-uniform: scalar registers
+        uint4 Ln, Fc;      // wave-uniform: scalar registers
+        uint32_t rhh_c, gp_c;
         auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
             constexpr int U = decltype(ub)::value;
             wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
@@ -519,7 +535,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
 #endif
             const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
             // tap address constant of this plane and buffer (an integer below 2^24, exact in fp32)
-            const float2 rg = make_float2(__uint_as_float(Gc.x), static_cast<float>(static_cast<int>(Gc.y) + static_cast<int>(tile_base) + U * kBufBytes));
+            const float2 rg = make_float2(__uint_as_float(rhh_c), static_cast<float>(static_cast<int>(gp_c) + static_cast<int>(tile_base) + U * kBufBytes));
             if (!abl_nocomp) {
 #pragma unroll
                 for (int q = 0; q < PPT; ++q) {
@@ -527,9 +543,10 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                     GMPI_STAMP(5 + q);
                 }
             }
-            // the records of the next step (the table has D + 2 planes of records per band: no bounds tests)
-            const uint4* __restrict__ rn = myrec + static_cast<int64_t>(tt + 1) * kRecStep;
-            Fc = rn[1], Gc = rn[2], Ln = rn[kRecStep];
+            // the records of the next step (both tables are padded by two planes of records: no bounds tests)
+            gp_c = Ln.w;  // (Ln is still the record of plane tt + 1)
+            Ln = myrec[static_cast<int64_t>(tt + 2) * kRecStep];
+            Fc = mypl[(tt + 1) * kPlU4], rhh_c = mypl[(tt + 1) * kPlU4 + 1].x;
             static_assert(PPT == 2 && kNP <= 3, "pixel slots / check passes");
         };
         // (the per-pixel state must sit in registers through the plane loop: a reload there is a vector memory operation on the DMA's counter)
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         }
         __syncthreads();  // (also: the loader offsets are in place)
         issue(myrec[0], reinterpret_cast<const uint32_t*>(smem)[fresh_tid()], ic<0>{});  // plane 0
-        Fc = myrec[1], Gc = myrec[2], Ln = myrec[kRecStep];
+        Fc = mypl[0], rhh_c = mypl[1].x, gp_c = myrec[0].w, Ln = myrec[kRecStep];
         for (int t = 0; t < D; t += 2) {
             stage(t, ic<0>{});
             if (t + 1 < D) stage(t + 1, ic<1>{});
@@ -564,9 +581,9 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                     bool lane_bad = false;
                     for (int t = 0; t < D; ++t) {
                         const uint4 rl = myrec[static_cast<int64_t>(t) * kRecStep];
-                        const int dims = static_cast<int>(rl.z), ext = static_cast<int>(rl.w), nq = dims & 0xff, rows = (dims >> 8) & 0xff;
-                        const uint32_t clo = dims < 0 ? (ext & 0xff) : 0u, ncol = dims < 0 ? ((ext >> 8) & 0xff) : static_cast<uint32_t>(nq);
-                        const uint32_t llo = dims < 0 ? 4 * ((ext >> 16) & 0xff) : 0u, nline = dims < 0 ? 4 * ((ext >> 24) & 0xff) : static_cast<uint32_t>(4 * rows);
+                        const Shape h = shape_unpack(rl.z);
+                        const int nq = h.nq;
+                        const uint32_t clo = h.clo, ncol = h.ncol, llo = 4 * h.rlo, nline = 4 * h.nrow;
                         const unsigned char* org = reinterpret_cast<const unsigned char*>((static_cast<uint64_t>(rl.y) << 32) | rl.x);
                         for (int r = 0; r < kNP; ++r) {
                             const bool in = l_on && l_col < nq && (static_cast<uint32_t>(l_col) - clo < ncol) && (static_cast<uint32_t>(l_line + 4 * r * kRPP) - llo < nline);
@@ -630,12 +647,14 @@ static void band_grid(const KParams& p, int& bands_x, int& bands_y, int& n_bands
     bands_x = (p.W + NSB * SBW - 1) / (NSB * SBW), bands_y = (p.H + SBH - 1) / SBH;
     n_bands = bands_x * bands_y * p.N;
 }
-// workspace: [n_bands] header words (padded to 256 bytes), then (n_bands * D + 2) * NSB records of 64 bytes
-static uint64_t ws_hdr_bytes(int n_bands) { return (static_cast<uint64_t>(n_bands) * 4 + 255) / 256 * 256; }
+// workspace: [n_bands] header words | (N * D + 2) plane records of 32 bytes | (n_bands * D + 2) * NSB box records of 16 bytes (each part 256-aligned)
+static uint64_t align256(uint64_t v) { return (v + 255) / 256 * 256; }
+static uint64_t ws_hdr_bytes(int n_bands) { return align256(static_cast<uint64_t>(n_bands) * 4); }
+static uint64_t ws_pl_bytes(const KParams& p) { return align256((static_cast<uint64_t>(p.N) * p.D + 2) * kPlU4 * 16); }
 static uint64_t ws_bytes(const KParams& p) {
     int bx, by, nb;
     band_grid(p, bx, by, nb);
-    return ws_hdr_bytes(nb) + (static_cast<uint64_t>(nb) * p.D + 2) * NSB * (kRecU4 * 16);
+    return ws_hdr_bytes(nb) + ws_pl_bytes(p) + (static_cast<uint64_t>(nb) * p.D + 2) * NSB * 16;
 }
 
 template <typename TexT>
@@ -647,19 +666,18 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
     const bool acf = p.flags & 1u;
     const float cx = acf ? static_cast<float>(p.Wt - 1) * 0.5f : static_cast<float>(p.Wt), cy = acf ? static_cast<float>(p.Ht - 1) * 0.5f : static_cast<float>(p.Ht);
     uint32_t* hdr = static_cast<uint32_t*>(p.ws);
-    uint4* recs = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands));
-    // 1. the geometry table (a few microseconds: one thread per band, plane and sub-block)
-    hipError_t e = hipMemsetAsync(hdr, 0, ws_hdr_bytes(n_bands), stream);
-    if (e != hipSuccess) return e;
-    const int64_t total = static_cast<int64_t>(n_bands) * p.D * NSB;
-    const dim3 tgrid(static_cast<unsigned>((total + 255) / 256)), tblock(256);
-    if (acf) hipLaunchKernelGGL((band_table_kernel<TexT, true>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr);
-    else hipLaunchKernelGGL((band_table_kernel<TexT, false>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr);
+    uint4* pl = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands));
+    uint4* recs = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands) + ws_pl_bytes(p));
+    // 1. the geometry table (one workgroup per band; writes every word the render kernel reads but the two planes of padding, whose content
+    //    is never used)
+    const dim3 tgrid(static_cast<unsigned>(n_bands)), tblock(256);
+    if (acf) hipLaunchKernelGGL((band_table_kernel<TexT, true>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr);
+    else hipLaunchKernelGGL((band_table_kernel<TexT, false>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr);
     // 2. the render
     const int sel = (p.flags & 1u ? 4 : 0) | (p.flags & (1u << 4) ? 2 : 0) | (p.flags & (1u << 3) ? 1 : 0);  // align_corners, strict order, range check
     switch (sel) {
 #define GMPI_BAND_CASE(I, AC_, ST_, CK_) \
-    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, hdr); break;
+    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr); break;
         GMPI_BAND_CASE(0, false, false, false) GMPI_BAND_CASE(1, false, false, true) GMPI_BAND_CASE(2, false, true, false) GMPI_BAND_CASE(3, false, true, true)
         GMPI_BAND_CASE(4, true, false, false) GMPI_BAND_CASE(5, true, false, true) GMPI_BAND_CASE(6, true, true, false) GMPI_BAND_CASE(7, true, true, true)
 #undef GMPI_BAND_CASE
