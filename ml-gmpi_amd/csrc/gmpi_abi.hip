@@ -4,6 +4,7 @@
 
 #include "../../include/gmpi_render.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace gmpi {
@@ -21,6 +22,7 @@ bool dma_variant_supports(const KParams& p, int dtype);                     // r
 hipError_t launch_band(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_band.hip
 bool band_variant_supports(const KParams& p, int dtype);                    // render_band.hip
 uint64_t band_workspace_bytes(const KParams& p);                            // render_band.hip
+uint32_t* band_gate_words(const KParams& p);                                // render_band.hip
 
 // ---- min/max of the normalised grid on the last plane (mpi.py:103-109 diagnostics) --------------
 template <bool AC>
@@ -246,8 +248,11 @@ static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, 
     p.flags = q->flags;
     p.ws = q->workspace;
     p.ws_bytes = q->workspace != nullptr ? q->workspace_bytes : 0;
+    p.gate = nullptr, p.gate_gen = 0, p.gate_sense = 0;
     return GMPI_OK;
 }
+
+constexpr int64_t kAutoBandMin = 512;  // bands (of 256 x 8 pixels) from which AUTO takes the band kernel: two workgroups on every CU
 
 static int hip_rc(hipError_t e) { return e == hipSuccess ? GMPI_OK : GMPI_E_LAUNCH - static_cast<int>(e); }
 
@@ -280,6 +285,23 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
                          : params->rgba_dtype == GMPI_DTYPE_F32 ? (strips <= 512 || (strips > 1536 && strips <= 2048))
                                                                 : strips <= 1024;
         variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
+        // Large launches over bf16 volumes, when the caller lends a workspace: the band kernel (256 x 8 pixel bands, LDS-DMA; 0.87 ms on
+        // BASELINE config 3 where the tile kernel takes 1.02) -- for the views it can stage.  Whether a view's texel boxes fit the band
+        // kernel's buffers depends on the camera (tilt shears the boxes) and is only known on the device, so AUTO launches BOTH kernels and
+        // lets the band kernel's table kernel share out the views through a gate word per view (KParams::gate): views with a box that does
+        // not fit fall to the tile kernel, the others' tile workgroups exit at once (an empty second launch costs a few microseconds).
+        const int64_t bands = static_cast<int64_t>(p.N) * ((p.W + 255) / 256) * ((p.H + 7) / 8);
+        if (variant == GMPI_VARIANT_LDS && params->rgba_dtype == GMPI_DTYPE_BF16 && bands >= kAutoBandMin &&
+            band_variant_supports(p, params->rgba_dtype)) {
+            static std::atomic<uint32_t> gate_counter{0x6d2b79f5u};
+            uint32_t gen = gate_counter.fetch_add(1u, std::memory_order_relaxed);
+            KParams pb = p;
+            pb.gate = band_gate_words(p), pb.gate_gen = gen, pb.gate_sense = 0u;
+            const hipError_t e = launch_band(pb, params->rgba_dtype, 0, st);
+            if (e != hipSuccess) return hip_rc(e);
+            pb.gate_sense = 1u;
+            return hip_rc(launch_lds(pb, params->rgba_dtype, 0, st));
+        }
     }
     if (variant == GMPI_VARIANT_GATHER) {
         if (p.N > 65535) return GMPI_E_SHAPE;  // the gather kernel puts the view index in grid.z
@@ -434,6 +456,7 @@ int gmpi_query(int32_t what) {
         case 6: return 1;  // GMPI_VARIANT_WAVE is built in
         case 7: return 1;  // GMPI_VARIANT_DMA is built in
         case 8: return 1;  // GMPI_VARIANT_BAND is built in
+        case 9: return static_cast<int>(kAutoBandMin);
         default: return -1;
     }
 }

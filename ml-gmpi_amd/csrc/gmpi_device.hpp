@@ -36,7 +36,30 @@ struct KParams {
     uint32_t flags;
     void* ws;           // caller's workspace (GmpiRenderParams.workspace): the band kernel's geometry table
     uint64_t ws_bytes;
+    // View gate (GMPI_VARIANT_AUTO's two-kernel launches, gmpi_abi.hip): the band kernel's table kernel stamps gate[n] = gate_gen for every view
+    // with a box that does not fit the band kernel's staging buffers; a render kernel takes view n iff (gate[n] == gate_gen) == (gate_sense != 0).
+    // Whatever the workspace held before, exactly one of the two kernels renders each view.  gate == nullptr: every view.
+    uint32_t* gate;
+    uint32_t gate_gen, gate_sense;
 };
+
+// blockIdx -> work item (pixel tile / band), "per view group" form: XCD x = blockIdx % 8 (workgroups are dealt round-robin to the 8 XCDs)
+// gets a contiguous run of the items of EVERY group of views that share an MPI, so that row-major neighbours meet in one L2 AND the XCDs walk
+// the views together -- a launch that only renders some of the views (gate) still fills every XCD.  Returns n_items for "no item".
+__device__ __forceinline__ int xcd_item_per_group(int block, int group_items, int n_items) {
+    const int per_xcd = (group_items + 7) / 8, n_groups = (n_items + group_items - 1) / group_items;
+    const int jb = block / 8, grp = jb / per_xcd, rr = jb - grp * per_xcd;
+    const int in_group = (block % 8) * per_xcd + rr;
+    const int item = grp * group_items + in_group;
+    return (grp >= n_groups || in_group >= group_items || item >= n_items) ? n_items : item;
+}
+inline __host__ unsigned xcd_grid_per_group(int group_items, int n_items) {
+    return static_cast<unsigned>(((group_items + 7) / 8) * 8 * ((n_items + group_items - 1) / group_items));
+}
+
+__device__ __forceinline__ bool view_gated_out(const KParams& p, int n) {
+    return p.gate != nullptr && ((p.gate[n] == p.gate_gen) != (p.gate_sense != 0u));
+}
 
 // MPI sampled by view n: view_to_mpi[n], or n / views_per_mpi.  An index outside [0, M) would address dhw and the volume
 // out of bounds: it is clamped and reported (status bit 8 = GMPI_STATUS_BAD_VIEW_INDEX) instead.

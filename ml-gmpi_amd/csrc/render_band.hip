@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256) void band_table_kernel(const KParams p, const 
         }
     }
     const int any_unfit = __syncthreads_or(unfit ? 1 : 0);
-    if (threadIdx.x == 0) hdr[band_id] = static_cast<uint32_t>(any_unfit);
+    if (threadIdx.x == 0) {
+        hdr[band_id] = static_cast<uint32_t>(any_unfit);
+        if (any_unfit && p.gate != nullptr) p.gate[n] = p.gate_gen;  // (AUTO: the whole view goes to the tile kernel; gmpi_device.hpp)
+    }
 }
 
 template <typename TexT, bool AC, bool STRICT, bool CHECK>
@@ -233,19 +236,14 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
     // ---- blockIdx -> band.  XCD x = blockIdx % 8 gets a contiguous run of the bands of EVERY view (group of views that share an MPI): row-major
     //      neighbours share halo rows in one L2, and the XCDs walk the views together (measured 4 % faster than one run of all bands per XCD,
     //      where different XCDs read different views at the same time) ----
-    const int group_bands = bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1);
-    const int per_xcd = (group_bands + 7) / 8;                      // bands of one group per XCD
-    const int n_groups = (n_bands + group_bands - 1) / group_bands;
-    const int jb = blockIdx.x / 8, grp = jb / per_xcd, rr = jb - grp * per_xcd;
-    const int in_group = (blockIdx.x % 8) * per_xcd + rr;
-    int band_id = grp * group_bands + in_group;
-    if (grp >= n_groups || in_group >= group_bands) band_id = n_bands;
+    int band_id = xcd_item_per_group(blockIdx.x, bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands);
 #ifdef GMPI_TUNE  // (experiment: one contiguous run of ALL bands per XCD)
     if (p.flags & (1u << 19)) band_id = static_cast<int>(blockIdx.x % 8) * ((n_bands + 7) / 8) + static_cast<int>(blockIdx.x / 8);
 #endif
     if (band_id >= n_bands) return;
     int n, brem;
     band_to_view(p, band_id, bands_x * bands_y, n, brem);
+    if (view_gated_out(p, n)) return;  // (AUTO: a view with a box that does not fit is the tile kernel's)
     const int byi = brem / bands_x, bxi = brem - byi * bands_x;
 
     const int tid = threadIdx.x;
@@ -647,27 +645,26 @@ static void band_grid(const KParams& p, int& bands_x, int& bands_y, int& n_bands
     bands_x = (p.W + NSB * SBW - 1) / (NSB * SBW), bands_y = (p.H + SBH - 1) / SBH;
     n_bands = bands_x * bands_y * p.N;
 }
-// workspace: [n_bands] header words | (N * D + 2) plane records of 32 bytes | (n_bands * D + 2) * NSB box records of 16 bytes (each part 256-aligned)
+// workspace: [n_bands] header words + [N] view gate words | (N * D + 2) plane records of 32 bytes | (n_bands * D + 2) * NSB box records of 16 bytes (each part 256-aligned)
 static uint64_t align256(uint64_t v) { return (v + 255) / 256 * 256; }
-static uint64_t ws_hdr_bytes(int n_bands) { return align256(static_cast<uint64_t>(n_bands) * 4); }
+static uint64_t ws_hdr_bytes(int n_bands, int n_views) { return align256((static_cast<uint64_t>(n_bands) + n_views) * 4); }
 static uint64_t ws_pl_bytes(const KParams& p) { return align256((static_cast<uint64_t>(p.N) * p.D + 2) * kPlU4 * 16); }
 static uint64_t ws_bytes(const KParams& p) {
     int bx, by, nb;
     band_grid(p, bx, by, nb);
-    return ws_hdr_bytes(nb) + ws_pl_bytes(p) + (static_cast<uint64_t>(nb) * p.D + 2) * NSB * 16;
+    return ws_hdr_bytes(nb, p.N) + ws_pl_bytes(p) + (static_cast<uint64_t>(nb) * p.D + 2) * NSB * 16;
 }
 
 template <typename TexT>
 static hipError_t launch_t(const KParams& p, hipStream_t stream) {
     int bands_x, bands_y, n_bands;
     band_grid(p, bands_x, bands_y, n_bands);
-    const int group_bands = bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1);
-    const dim3 grid(static_cast<unsigned>(((group_bands + 7) / 8) * 8 * ((n_bands + group_bands - 1) / group_bands))), block(kNT);
+    const dim3 grid(xcd_grid_per_group(bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands)), block(kNT);
     const bool acf = p.flags & 1u;
     const float cx = acf ? static_cast<float>(p.Wt - 1) * 0.5f : static_cast<float>(p.Wt), cy = acf ? static_cast<float>(p.Ht - 1) * 0.5f : static_cast<float>(p.Ht);
     uint32_t* hdr = static_cast<uint32_t*>(p.ws);
-    uint4* pl = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands));
-    uint4* recs = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands) + ws_pl_bytes(p));
+    uint4* pl = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands, p.N));
+    uint4* recs = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands, p.N) + ws_pl_bytes(p));
     // 1. the geometry table (one workgroup per band; writes every word the render kernel reads but the two planes of padding, whose content
     //    is never used)
     const dim3 tgrid(static_cast<unsigned>(n_bands)), tblock(256);
@@ -689,11 +686,21 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
 
 uint64_t band_workspace_bytes(const KParams& p) { return band::ws_bytes(p); }
 
+// the view gate words of the workspace (KParams::gate of an AUTO launch)
+uint32_t* band_gate_words(const KParams& p) {
+    int bx, by, nb;
+    band::band_grid(p, bx, by, nb);
+    return static_cast<uint32_t*>(p.ws) + nb;
+}
+
 bool band_variant_supports(const KParams& p, int dtype) {
-    if (dtype == 2) return false;
+    // bf16 volumes only.  fp16: a d16 load yields the half's bits, not an fp32 value (render_lds.hip converts while staging).  fp32: a plane's
+    // boxes are twice the bytes -- two staging buffers of 15 rows no longer leave room for two workgroups per CU, and with 7 rows hardly a
+    // band fits -- and the tile kernel already reaches 0.6-0.7 of the HBM rate there (profiles/README.md), so the geometry below stays untested.
+    if (dtype != 1) return false;
     if (p.ws == nullptr || p.ws_bytes < band::ws_bytes(p) || reinterpret_cast<uintptr_t>(p.ws) % 256 != 0) return false;  // needs the caller's workspace
-    if (static_cast<int64_t>(p.N) * p.D * ((p.W + 255) / 256) * ((p.H + 7) / 8) > (int64_t(1) << 28)) return false;  // fp16 volumes: render_lds.hip (a d16 load yields the half's bits, not an fp32 value)
-    const int es = dtype == 0 ? 4 : 2, tpi = 16 / es;
+    if (static_cast<int64_t>(p.N) * p.D * ((p.W + 255) / 256) * ((p.H + 7) / 8) > (int64_t(1) << 28)) return false;  // record indices stay in 32 bits
+    const int es = 2, tpi = 16 / es;
     if (p.Wt % tpi != 0) return false;
     if (reinterpret_cast<uintptr_t>(p.rgba) % 16 != 0) return false;
     if (p.s_row % tpi != 0 || p.s_chan % tpi != 0 || p.s_plane % tpi != 0 || p.s_mpi % tpi != 0) return false;
@@ -710,7 +717,8 @@ hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t strea
 #else
     (void)tune;
 #endif
-    return dtype == 1 ? band::launch_t<bf16_t>(p, stream) : band::launch_t<float>(p, stream);
+    if (dtype != 1) return hipErrorInvalidValue;
+    return band::launch_t<bf16_t>(p, stream);
 }
 
 }  // namespace gmpi

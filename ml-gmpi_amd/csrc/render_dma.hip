@@ -506,8 +506,9 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
 }  // namespace dma
 
 bool dma_variant_supports(const KParams& p, int dtype) {
-    if (dtype == 2) return false;  // fp16 volumes: render_lds.hip
-    const int es = dtype == 0 ? 4 : 2, tpi = 16 / es;
+    // bf16 volumes only (fp16: render_lds.hip; the fp32 instance of this kernel does not pass its parity check yet and is not dispatched)
+    if (dtype != 1) return false;
+    const int es = 2, tpi = 16 / es;
     if (p.Wt % tpi != 0) return false;
     if (reinterpret_cast<uintptr_t>(p.rgba) % 16 != 0) return false;
     if (p.s_row % tpi != 0 || p.s_chan % tpi != 0 || p.s_plane % tpi != 0 || p.s_mpi % tpi != 0) return false;

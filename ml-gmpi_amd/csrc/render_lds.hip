@@ -163,10 +163,14 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
 
     // ---- blockIdx -> tile: XCD x (blockIdx % 8) gets the contiguous run [x*per, (x+1)*per) of tiles, so
     //      neighbouring tiles (shared halo texels) meet in one L2 ------------------------------------------
-    const int per_xcd = (n_tiles + 7) / 8;
-    const int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    if (tile_id >= n_tiles) return;
     const int tiles_per_view = tiles_x * tiles_y;
+    const int per_xcd = (n_tiles + 7) / 8;
+    int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (blockIdx.x >= static_cast<unsigned>(per_xcd * 8)) tile_id = n_tiles;
+    // (a gated launch -- AUTO's fallback for the views the band kernel leaves -- renders only some of the views: there every view's tiles are
+    //  spread over all XCDs, or one view would run on the one or two XCDs that hold its run)
+    if (p.gate != nullptr) tile_id = xcd_item_per_group(blockIdx.x, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
+    if (tile_id >= n_tiles) return;
     // Views that share one MPI (video paths: views_per_mpi > 1) are interleaved per tile position, so the workgroups
     // that need (nearly) the same texels of a plane run next to each other in time and on the same XCD: the volume is
     // then read from HBM about once per group of views instead of once per view (the rest hits in that XCD's L2).
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         n = tile_id / tiles_per_view;
         trem = tile_id - n * tiles_per_view;
     }
+    if (view_gated_out(p, n)) return;  // (AUTO: this view is the band kernel's)
     const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
 
     const int tid = threadIdx.x;
@@ -636,7 +641,9 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     constexpr int TH = kNT / TW;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int n_tiles = tiles_x * tiles_y * p.N;
-    const dim3 grid(((n_tiles + 7) / 8) * 8), block(kNT);
+    const unsigned grid_x = p.gate != nullptr ? xcd_grid_per_group(tiles_x * tiles_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles)
+                                              : static_cast<unsigned>(((n_tiles + 7) / 8) * 8);
+    const dim3 grid(grid_x), block(kNT);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
     if (ac && strict) hipLaunchKernelGGL((render_lds_kernel<TexT, true, true, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
     else if (ac) hipLaunchKernelGGL((render_lds_kernel<TexT, true, false, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);

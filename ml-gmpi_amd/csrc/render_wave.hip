@@ -186,6 +186,7 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
         n = tile_id / tiles_per_view;
         trem = tile_id - n * tiles_per_view;
     }
+    if (view_gated_out(p, n)) return;  // (AUTO: this view is the band kernel's)
     const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
 
     uint32_t bad = 0;
