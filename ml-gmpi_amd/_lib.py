@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_PKG, "libgmpi_render.so")
 _LIB = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 FLAG_ALIGN_CORNERS, FLAG_OUT_PM1, FLAG_CHECK_LAST_PLANE, FLAG_CHECK_RANGE, FLAG_STRICT_ORDER = 1, 2, 4, 8, 16
 STATUS_OUT_OF_LAST_PLANE, STATUS_RGBA_RANGE, STATUS_CAMERA_BEHIND_PLANE, STATUS_BAD_VIEW_INDEX = 1, 2, 4, 8
@@ -22,6 +22,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS, 
 
 EXPORTS = (
     "gmpi_mpi_render_launch",
+    "gmpi_render_workspace_bytes",
     "gmpi_mpi_render_backward_launch",
     "gmpi_last_plane_uv_minmax_launch",
     "gmpi_rgba_range_check_launch",
@@ -120,6 +121,8 @@ def load_library():
     vp = ctypes.c_void_p
     lib.gmpi_mpi_render_launch.restype = ctypes.c_int
     lib.gmpi_mpi_render_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp]
+    lib.gmpi_render_workspace_bytes.restype = ctypes.c_uint64
+    lib.gmpi_render_workspace_bytes.argtypes = [ctypes.POINTER(GmpiRenderParams)]
     lib.gmpi_mpi_render_backward_launch.restype = ctypes.c_int
     lib.gmpi_mpi_render_backward_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp, vp, vp,
                                                     ctypes.POINTER(ctypes.c_int64), vp]

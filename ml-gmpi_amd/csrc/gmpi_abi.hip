@@ -334,8 +334,10 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
 uint64_t gmpi_render_workspace_bytes(const GmpiRenderParams* params) {
     KParams p;
     if (to_kparams(params, p, true) != GMPI_OK || p.N == 0) return 0;
-    if (params->rgba_dtype == GMPI_DTYPE_F16) return 0;
-    return band_workspace_bytes(p);
+    if (params->rgba_dtype != GMPI_DTYPE_BF16) return 0;  // (the band kernel takes bf16 volumes only)
+    const int64_t bands = static_cast<int64_t>(p.N) * ((p.W + 255) / 256) * ((p.H + 7) / 8);
+    if (params->variant == GMPI_VARIANT_BAND || (params->variant == GMPI_VARIANT_AUTO && bands >= kAutoBandMin)) return band_workspace_bytes(p);
+    return 0;
 }
 
 int gmpi_mpi_render_backward_launch(const GmpiRenderParams* params, const float* grad_rgb, const float* grad_depth,

@@ -24,6 +24,19 @@ from . import _lib
 _DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 
 
+# Scratch lent to the C ABI (GmpiRenderParams.workspace), one per device and stream: a call in flight on another stream must not share it.
+_WORKSPACES = {}
+
+
+def _workspace(dev: torch.device, stream: int, need: int) -> torch.Tensor:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)  # (the caching allocator hands out 512-byte aligned blocks)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 def _cat(parts: Union[torch.Tensor, Sequence[torch.Tensor]]) -> torch.Tensor:
     if isinstance(parts, torch.Tensor):
         return parts
@@ -34,7 +47,8 @@ class MPI(nn.Module):
     """Drop-in for `gmpi.core.mpi.MPI`.
 
     Extra constructor knobs (all optional; defaults reproduce the reference's behaviour):
-      variant        "auto" | "gather" | "lds" | "wave"  -- kernel selection (GMPI_VARIANT_*)
+      variant        "auto" | "gather" | "lds" | "wave" | "dma" | "band"  -- kernel selection (GMPI_VARIANT_*); "auto" takes the band kernel
+                     for large launches over bf16 volumes and lets it share the views with the tile kernel (gmpi_render.h)
       strict_order   one rounding per reference op also in the blend (bit-identical to the oracle)
       range_check    "touched" (alpha/rgba range asserted on the texels the render samples, free), "full" (extra
                      exhaustive pass = the reference's min/max over the whole volume, mpi.py:185-187 /
@@ -207,6 +221,11 @@ class MPI(nn.Module):
         p.transmittance_out = T.data_ptr() if T is not None else None
         p.status = status.data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream if on_device else 0
+        if on_device:  # scratch for the kernels that want some (the band kernel's geometry table): 0 bytes for most launches
+            need = int(lib.gmpi_render_workspace_bytes(ctypes.byref(p)))
+            if need:
+                ws = _workspace(dev, stream, need)
+                p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
         with (torch.cuda.device(dev) if on_device else contextlib.nullcontext()):
             if self.range_check == "full":
                 vol = rgba if rgba.is_contiguous() else rgba.contiguous()

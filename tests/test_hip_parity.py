@@ -24,10 +24,14 @@ def _lib():
     return L
 
 
-def variants():
+def variants(bf16=False):
+    """Kernel variants built into the library; bf16=True adds the ones that only take bf16 volumes (LDS-DMA tile and band kernels)."""
     L = _lib()
     lib = L.load_library()
-    return ["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
+    v = ["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
+    if bf16:
+        v += (["dma"] if lib.gmpi_query(7) > 0 else []) + (["band"] if lib.gmpi_query(8) > 0 else []) + ["auto"]
+    return v
 
 
 def hip_render(rgba, dhw, ray_dir, eye, zdir, *, ac=True, variant="gather", strict=False, view_to_mpi=None,
@@ -50,7 +54,7 @@ def hip_render(rgba, dhw, ray_dir, eye, zdir, *, ac=True, variant="gather", stri
         except GmpiError as e:
             # shapes the LDS kernel cannot stage (texture width not a multiple of 4, unaligned strides) must be
             # refused when forced and handled by "auto" (which then picks the gather kernel)
-            if variant not in ("lds", "wave") or "GMPI_E_VARIANT" not in str(e):
+            if variant not in ("lds", "wave", "dma", "band") or "GMPI_E_VARIANT" not in str(e):
                 raise
             mpi.variant = "auto"
             out = mpi.render_views(*args, **kw)
@@ -139,7 +143,7 @@ def test_half_storage_is_exact_upcast(dtype):
     rgba, dhw, ray, eye, zd = _random_case(seed=7, B=2, D=16, S=128)
     stored = rgba.to(dtype)
     orc = oracle.render(stored.float(), dhw, ray, eye, zd)  # reference upcasts: mpi_renderer.py:446
-    for variant in variants():
+    for variant in variants(bf16=dtype == torch.bfloat16):
         out = hip_render(stored, dhw, ray, eye, zd, variant=variant, strict=True)
         assert np.array_equal(out["color"], orc["color"]) and np.array_equal(out["depth"], orc["depth"]), variant
 
