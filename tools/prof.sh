@@ -21,7 +21,7 @@ pmc() { # workload name counters...
   timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$wl/pmc_$name -o p -- python bench.py $ARGS --workload $wl > $OUT/$wl/bench_$name.log 2>&1
   echo "$wl $name rc=$?"
 }
-for wl in cfg3 cfg2 cfg3_f32 cfg4 cfg5; do
+for wl in ${WORKLOADS:-cfg3 cfg2 cfg3_f32 cfg4 cfg5}; do
   pmc $wl fetch FETCH_SIZE
   pmc $wl valu SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD
 done

@@ -13,21 +13,34 @@ out = sys.argv[1]
 
 
 def render_kernel(name):
-    return "render_" in name and "backward" not in name
+    return ("render_" in name or "band_table" in name) and "backward" not in name
+
+
+# issue cost per wave64 VALU instruction and SIMD of each kernel's instruction mix (profiles/r03_probe.txt, r02b_mix_rate_steady.txt):
+# fp32 fma / mul / add 1.05-1.1 ns, integer / conversion / floor / compare 1.6-1.9 ns
+VALU_NS = {"render_band_kernel": 1.18, "render_lds_kernel": 1.30, "render_wave_kernel": 1.30, "render_dma_kernel": 1.25}
 
 
 def pmc_means(d):
+    """Counter totals of ONE render step = all kernels of the step (AUTO on large bf16 launches: table kernel + band kernel + the tile kernel's
+    gated launch), divided by the number of dispatches of the step's dominant kernel."""
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         return {}, None
-    acc = defaultdict(lambda: defaultdict(float))
-    kname = None
+    tot = defaultdict(lambda: defaultdict(float))       # counter -> kernel -> total
+    disp = defaultdict(set)                             # kernel -> dispatch ids
     for row in csv.DictReader(open(files[0])):
-        if not render_kernel(row["Kernel_Name"]):
+        k = row["Kernel_Name"]
+        if not render_kernel(k):
             continue
-        kname = row["Kernel_Name"]
-        acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-    return {c: sum(v.values()) / len(v) for c, v in acc.items()}, kname
+        tot[row["Counter_Name"]][k] += float(row["Counter_Value"])
+        disp[k].add(row["Dispatch_Id"])
+    if not tot:
+        return {}, None
+    any_counter = next(iter(tot.values()))
+    kname = max(any_counter, key=any_counter.get)       # the kernel that carries the step
+    steps = len(disp[kname])
+    return {c: sum(v.values()) / steps for c, v in tot.items()}, kname
 
 
 for f in sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)):
@@ -76,6 +89,7 @@ for wl in ("cfg3", "cfg2", "cfg3_f32", "cfg4", "cfg5"):
                 extra = f"  -> x2 = {v * 1024 * 2 / 1e9:.3f} GB per launch"
             if c == "SQ_INSTS_VALU":
                 ent["valu_insts_per_launch"] = int(v)
+                ent["valu_ns_per_inst"] = next((ns for key, ns in VALU_NS.items() if kname and key in kname), 1.30)
             print(f"  {os.path.basename(p):10s} {c:32s} {v:18.1f}{extra}")
     log = os.path.join(d, "bench_fetch.log")
     if os.path.isfile(log):
