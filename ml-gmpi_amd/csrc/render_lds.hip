@@ -167,9 +167,20 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     const int per_xcd = (n_tiles + 7) / 8;
     int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (blockIdx.x >= static_cast<unsigned>(per_xcd * 8)) tile_id = n_tiles;
-    // (a gated launch -- AUTO's fallback for the views the band kernel leaves -- renders only some of the views: there every view's tiles are
-    //  spread over all XCDs, or one view would run on the one or two XCDs that hold its run)
-    if (p.gate != nullptr) tile_id = xcd_item_per_group(blockIdx.x, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
+    // Per-group order (every view's tiles spread over all XCDs, the XCDs walk the views together):
+    //  * a gated launch -- AUTO's fallback for the views the band kernel leaves -- renders only some of the views: with one run of all tiles
+    //    per XCD a single view would run on the one or two XCDs that hold it;
+    //  * fp32 volumes: measured 1.5 % (config 3 shape) to 3.7 % (config 5) faster than one run per XCD, 16-bit volumes 1 % slower
+    //    (profiles/r03_xcd_order.txt) -- so 16-bit volumes keep the run per XCD.
+    if (p.gate != nullptr || sizeof(TexT) == 4)
+        tile_id = xcd_item_per_group(blockIdx.x, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
+#ifdef GMPI_TUNE  // (experiment: flag bit 19 flips the order)
+    if (p.flags & (1u << 19)) {
+        tile_id = (p.gate != nullptr || sizeof(TexT) == 4) ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8
+                                                           : xcd_item_per_group(blockIdx.x, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
+        if (blockIdx.x >= static_cast<unsigned>(per_xcd * 8) && (p.gate != nullptr || sizeof(TexT) == 4)) tile_id = n_tiles;
+    }
+#endif
     if (tile_id >= n_tiles) return;
     // Views that share one MPI (video paths: views_per_mpi > 1) are interleaved per tile position, so the workgroups
     // that need (nearly) the same texels of a plane run next to each other in time and on the same XCD: the volume is
@@ -641,7 +652,7 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     constexpr int TH = kNT / TW;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int n_tiles = tiles_x * tiles_y * p.N;
-    const unsigned grid_x = p.gate != nullptr ? xcd_grid_per_group(tiles_x * tiles_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles)
+    const unsigned grid_x = (p.gate != nullptr || sizeof(TexT) == 4 || (p.flags & (1u << 19))) ? xcd_grid_per_group(tiles_x * tiles_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles)
                                               : static_cast<unsigned>(((n_tiles + 7) / 8) * 8);
     const dim3 grid(grid_x), block(kNT);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
@@ -655,7 +666,7 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
 hipError_t launch_lds(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
 #ifdef GMPI_TUNE  // profiling builds: GMPI_TUNE_WAVE + 256 no memory traffic, + 512 no compositing (loader only), + 1024 no LDS stores
-    p.flags |= static_cast<uint32_t>((tune >> 8) & 7) << 16;
+    p.flags |= static_cast<uint32_t>((tune >> 8) & 15) << 16;
 #endif
     // Shipped instances only: fp32 volumes keep fp32 planes in LDS (LAYOUT 0, 3 workgroups per CU), 16-bit volumes their raw
     // texels, interleaved (LAYOUT 1, 4 workgroups per CU); 32x16 pixel tiles, one plane of prefetch -- the values the round-1

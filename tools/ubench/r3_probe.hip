@@ -189,6 +189,13 @@ template <int MODE, int EXTRA> static void run_taps(const char* name) {
 }
 
 // ---------------------------------------------------------------- streaming read
+__global__ void fill_random(uint32_t* p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint64_t z = i + 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        p[i] = static_cast<uint32_t>(z >> 32) & 0x3f7f3f7fu;  // two bf16 values in [0, 1)
+    }
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ v, size_t nvec, uint32_t* sink) {
     __shared__ __attribute__((aligned(16))) uint4 lds[8 * 256];
@@ -206,6 +213,10 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ v
             const uint32_t* p = reinterpret_cast<const uint32_t*>(v + (i - threadIdx.x));
 #pragma unroll
             for (int u = 0; u < 32; ++u) acc |= __builtin_nontemporal_load(p + u * 256 + threadIdx.x);
+        } else if (MODE == 5) {  // plain (cached) dword loads: the shape of the bf16 tile loader of render_lds.hip
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(v + (i - threadIdx.x));
+#pragma unroll
+            for (int u = 0; u < 32; ++u) acc |= p[u * 256 + threadIdx.x];
         } else if (MODE == 4) {
             const uint2* p = reinterpret_cast<const uint2*>(v + (i - threadIdx.x));
 #pragma unroll
@@ -245,15 +256,20 @@ int main(int argc, char** argv) {
         run_taps<0, 36>("bf16 planar, 16 x ds_read_u16_d16_hi"); run_taps<1, 36>("bf16 texels, 2 x ds_read2_b64 + 16 unpack"); run_taps<2, 36>("fp32 planar, 8 x ds_read2_b32"); run_taps<3, 36>("fp32 texels, 4 x ds_read_b128");
     } else if (!strcmp(what, "stream")) {
         const size_t bytes = (size_t)3221225472u;  // the bf16 volume of config 3
-        uint4* v; uint32_t* sink; CK(hipMalloc(&v, bytes)); CK(hipMalloc(&sink, 16)); CK(hipMemset(v, 1, bytes));
+        uint4* v; uint32_t* sink; CK(hipMalloc(&v, bytes)); CK(hipMalloc(&sink, 16));
+        fill_random<<<4096, 256>>>(reinterpret_cast<uint32_t*>(v), bytes / 4);  // (bf16 values in [0, 1): constant data would flatter the rate -- DVFS is data dependent)
+        CK(hipDeviceSynchronize());
         const size_t nvec = bytes / 16;
         const int mode = argc > 2 ? atoi(argv[2]) : -1;
+        const int only_b = argc > 3 ? atoi(argv[3]) : 0;
         for (int b : {2, 4, 8}) {
+            if (only_b && b != only_b) continue;
             if (mode < 0 || mode == 0) run_stream<0>("dwordx4", v, nvec, sink, b);
             if (mode < 0 || mode == 1) run_stream<1>("dwordx4 nt", v, nvec, sink, b);
             if (mode < 0 || mode == 2) run_stream<2>("LDS-DMA b128", v, nvec, sink, b);
             if (mode < 0 || mode == 3) run_stream<3>("dword nt", v, nvec, sink, b);
             if (mode < 0 || mode == 4) run_stream<4>("dwordx2", v, nvec, sink, b);
+            if (mode < 0 || mode == 5) run_stream<5>("dword", v, nvec, sink, b);
         }
     }
     return 0;
