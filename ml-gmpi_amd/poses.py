@@ -57,15 +57,17 @@ def _unit(v: torch.Tensor) -> torch.Tensor:
     return v / torch.norm(v, dim=-1, keepdim=True)
 
 
-def truncated_normal(n: int, mean: float, std: float, n_stds: float, device=_CPU) -> torch.Tensor:
+def truncated_normal(n: int, mean: float, std: float, n_stds: float, device=_CPU, cand: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[n,1] draws from N(mean, std) restricted to mean +- n_stds*std.
 
     Four candidates per sample (one `normal_()` call on [n,1,4], which is what fixes the RNG
     consumption), the first candidate strictly inside the bounds wins, and whatever is chosen is
     clipped to the closed interval.  With std == 0 every candidate equals `mean`.
+    `cand`: standard-normal candidates drawn by the caller ([m,1,4], consumed in place; `draw_angle_noise`).
     """
     assert std >= 0, f"{std}"
-    cand = torch.empty((n, 1, 4), dtype=torch.float32, device=device).normal_()
+    if cand is None:
+        cand = torch.empty((n, 1, 4), dtype=torch.float32, device=device).normal_()
     cand.mul_(std).add_(mean)
     lo = mean - 1 * n_stds * std
     hi = mean + n_stds * std
@@ -77,21 +79,40 @@ def truncated_normal(n: int, mean: float, std: float, n_stds: float, device=_CPU
     return out
 
 
+def draw_angle_noise(n: int, method: str, generator: Optional[torch.Generator] = None, device=_CPU) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The raw random numbers of ONE `sample_sphere_angles(random=True)` call, in its RNG order (yaw noise, then pitch noise): the
+    only part of pose sampling that touches the generator.  `generator=None` = torch's default CPU generator, like the reference."""
+    if method == "uniform":
+        return torch.rand((n, 1), device=device, generator=generator), torch.rand((n, 1), device=device, generator=generator)
+    if method in ("normal", "gaussian"):
+        return torch.randn((n, 1), device=device, generator=generator), torch.randn((n, 1), device=device, generator=generator)
+    if method == "truncated_gaussian":
+        return (torch.empty((n, 1, 4), dtype=torch.float32, device=device).normal_(generator=generator),
+                torch.empty((n, 1, 4), dtype=torch.float32, device=device).normal_(generator=generator))
+    raise ValueError(method)
+
+
+def angles_from_noise(noise_yaw: torch.Tensor, noise_pitch: torch.Tensor, yaw_mean, yaw_std, pitch_mean, pitch_std, *, method: str,
+                      n_stds: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(yaws, pitches) [m,1] from the raw draws of `draw_angle_noise` -- of one call, or of several calls concatenated along dim 0
+    (every operation is per element / per row, so the rows of a batch equal the rows of the separate calls bit for bit)."""
+    m = noise_yaw.shape[0]
+    if method == "uniform":
+        return (noise_yaw - 0.5) * 2 * n_stds * yaw_std + yaw_mean, (noise_pitch - 0.5) * 2 * n_stds * pitch_std + pitch_mean
+    if method in ("normal", "gaussian"):
+        return noise_yaw * yaw_std + yaw_mean, noise_pitch * pitch_std + pitch_mean
+    if method == "truncated_gaussian":
+        return (truncated_normal(m, yaw_mean, yaw_std, n_stds, noise_yaw.device, cand=noise_yaw),
+                truncated_normal(m, pitch_mean, pitch_std, n_stds, noise_pitch.device, cand=noise_pitch))
+    raise ValueError(method)
+
+
 def sample_sphere_angles(n: int, yaw_mean, yaw_std, pitch_mean, pitch_std, *, random: bool, method: str,
                          n_stds: float, horizontal_sweep: bool = True, device=_CPU) -> Tuple[torch.Tensor, torch.Tensor]:
     """(yaws, pitches), each [n,1] float32.  RNG order: yaws first, then pitches."""
     if random:
-        if method == "uniform":
-            yaws = (torch.rand((n, 1), device=device) - 0.5) * 2 * n_stds * yaw_std + yaw_mean
-            pitches = (torch.rand((n, 1), device=device) - 0.5) * 2 * n_stds * pitch_std + pitch_mean
-        elif method in ("normal", "gaussian"):
-            yaws = torch.randn((n, 1), device=device) * yaw_std + yaw_mean
-            pitches = torch.randn((n, 1), device=device) * pitch_std + pitch_mean
-        elif method == "truncated_gaussian":
-            yaws = truncated_normal(n, yaw_mean, yaw_std, n_stds, device)
-            pitches = truncated_normal(n, pitch_mean, pitch_std, n_stds, device)
-        else:
-            raise ValueError(method)
+        noise_yaw, noise_pitch = draw_angle_noise(n, method, None, device)
+        yaws, pitches = angles_from_noise(noise_yaw, noise_pitch, yaw_mean, yaw_std, pitch_mean, pitch_std, method=method, n_stds=n_stds)
     else:
         sweep = torch.linspace(-n_stds, n_stds, steps=n, device=device).reshape((n, 1))
         if horizontal_sweep:
@@ -175,6 +196,30 @@ def gen_sphere_path(n_cams: int, sphere_center: np.ndarray, sphere_r: Optional[f
         cam2sphere = look_at_centre(pos).cpu().numpy()
     c2w = np.matmul(sphere_to_mpi_frame(sphere_center), cam2sphere)
     return c2w, yaws, pitches
+
+
+def gen_sphere_paths_ahead(n_calls: int, n_cams: int, sphere_center: np.ndarray, sphere_r: Optional[float], yaw_mean, yaw_std, pitch_mean,
+                           pitch_std, sample_method: str, n_truncated_stds, generator: torch.Generator):
+    """The poses of the next `n_calls` calls of `gen_sphere_path(n_cams, ..., flag_rnd=True)` as they would come out if the default
+    generator were in `generator`'s state: the random draws are taken from `generator` call by call (its state after every call is
+    recorded), the arithmetic runs once over all calls.  Returns (c2w [n_calls, n_cams, 4, 4] float64 numpy, yaws, pitches as
+    [n_calls, n_cams, 1] float32, states: n_calls + 1 generator states -- states[j] before call j, states[j + 1] after it).
+    Bit-identical to n_calls separate calls (tests/test_host_geometry.py)."""
+    if sphere_r is None:
+        sphere_r = np.linalg.norm(sphere_center, ord=2)
+    with host_math():
+        states = [generator.get_state()]
+        ny, npi = [], []
+        for _ in range(n_calls):
+            a, b = draw_angle_noise(n_cams, sample_method, generator)
+            ny.append(a), npi.append(b)
+            states.append(generator.get_state())
+        yaws, pitches = angles_from_noise(torch.cat(ny, 0), torch.cat(npi, 0), yaw_mean, yaw_std, pitch_mean, pitch_std,
+                                          method=sample_method, n_stds=n_truncated_stds)
+        pos = sphere_positions(yaws, pitches, sphere_r)
+        cam2sphere = look_at_centre(pos).cpu().numpy()
+    c2w = np.matmul(sphere_to_mpi_frame(sphere_center), cam2sphere)
+    return (c2w.reshape(n_calls, n_cams, 4, 4), yaws.reshape(n_calls, n_cams, 1), pitches.reshape(n_calls, n_cams, 1), states)
 
 
 def yaw_pitch_from_w2c(w2c_mat: torch.Tensor, sphere_c: torch.Tensor):

@@ -127,29 +127,67 @@ def test_host_math_context_restores_the_intra_op_thread_count():
     assert torch.equal(a, b)
 
 
-def test_prefetched_poses_are_the_poses_the_calls_would_have_drawn():
-    """MPIRenderer.prefetch_poses: same RNG consumption, same order, same bits as drawing inside each call."""
+def test_look_ahead_poses_are_the_poses_the_calls_would_have_drawn():
+    """MPIRenderer's guarded pose look-ahead (started by itself when a request repeats, or by prefetch_poses): same poses, same RNG
+    stream as drawing inside each call, whatever else the program draws in between."""
     import ml_gmpi_amd
-    r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=4, device=torch.device("cpu"), ray_backend="torch")
-    r.set_cam(r.cam_fov, 8, 8)
-    args = (3, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
-    torch.manual_seed(77)
-    seq = [r.sample_cam_poses(*args) for _ in range(4)]
-    after_seq = torch.rand(3)
-    torch.manual_seed(77)
-    r.prefetch_poses(4, 3)
-    after_pre = torch.rand(3)
-    assert torch.equal(after_seq, after_pre)
-    for want in seq:
-        got = r.sample_cam_poses(*args)
-        for a, b in zip(want[:3], got[:3]):
-            assert torch.equal(a, b)
-        assert all(torch.equal(a, b) for a, b in zip(want[3], got[3]))
-    assert not r._pose_queue
-    # a call with other arguments discards the queue and draws for itself
-    r.prefetch_poses(2, 3)
-    torch.manual_seed(5)
-    a = r.sample_cam_poses(2, 0.0, 0.1, 0.0, 0.1, True)
-    torch.manual_seed(5)
-    b = r.sample_cam_poses(2, 0.0, 0.1, 0.0, 0.1, True)
-    assert torch.equal(a[2], b[2]) and not r._pose_queue
+    from ml_gmpi_amd import poses
+
+    def plain(r, n, hm, hs, vm, vs):  # one call the way the reference does it: straight from the default generator
+        c2w, yaws, pitches = poses.gen_sphere_path(n_cams=n, sphere_center=r.sphere_center, sphere_r=r.sphere_r, yaw_mean=hm, yaw_std=hs,
+                                                   pitch_mean=vm, pitch_std=vs, n_truncated_stds=r.cam_pose_n_truncated_stds, flag_rnd=True,
+                                                   sample_method=r.cam_sample_method)
+        return yaws, pitches, torch.FloatTensor(c2w)
+
+    for method in ("truncated_gaussian", "uniform", "normal"):
+        r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=4, device=torch.device("cpu"), ray_backend="torch", cam_sample_method=method)
+        r.set_cam(r.cam_fov, 8, 8)
+        args = (3, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std)
+        # 1. a loop of identical calls (the look-ahead starts at the second call and is refilled when it runs dry) with an unrelated
+        #    draw after every third call (which invalidates the queue: the call after it must draw for itself)
+        torch.manual_seed(77)
+        want, noise_want = [], []
+        for i in range(25):
+            want.append(plain(r, *args))
+            if i % 3 == 2:
+                noise_want.append(torch.rand(2))
+        end_want = torch.rand(3)
+        torch.manual_seed(77)
+        got, noise_got = [], []
+        for i in range(25):
+            got.append(r.sample_cam_poses(*args, True)[:3])
+            if i % 3 == 2:
+                noise_got.append(torch.rand(2))
+        end_got = torch.rand(3)
+        assert torch.equal(end_want, end_got) and all(torch.equal(a, b) for a, b in zip(noise_want, noise_got))
+        for w, g in zip(want, got):
+            assert all(torch.equal(a, b) for a, b in zip(w, g)), method
+        # 2. an undisturbed loop: the queue is actually used (and refilled)
+        torch.manual_seed(5)
+        want = [plain(r, *args) for _ in range(20)]
+        torch.manual_seed(5)
+        used = 0
+        for w in want:
+            before = None if r._spec is None else r._spec["idx"]
+            g = r.sample_cam_poses(*args, True)[:3]
+            used += int(r._spec is not None and before is not None and r._spec["idx"] == before + 1)
+            assert all(torch.equal(a, b) for a, b in zip(w, g)), method
+        assert used >= 14, used
+        # 3. prefetch_poses does not advance the generator; re-seeding between calls drops the queue
+        torch.manual_seed(9)
+        r.prefetch_poses(4, 3)
+        probe = torch.get_rng_state()
+        torch.manual_seed(9)
+        assert torch.equal(probe, torch.get_rng_state())
+        a = r.sample_cam_poses(*args, True)
+        torch.manual_seed(123)
+        w = plain(r, *args)
+        torch.manual_seed(123)
+        b = r.sample_cam_poses(*args, True)
+        assert all(torch.equal(x, y) for x, y in zip(w, b[:3])) and not torch.equal(a[2], b[2])
+        # 4. other arguments: the call draws for itself
+        torch.manual_seed(5)
+        w = plain(r, 2, 0.0, 0.1, 0.0, 0.1)
+        torch.manual_seed(5)
+        b = r.sample_cam_poses(2, 0.0, 0.1, 0.0, 0.1, True)
+        assert all(torch.equal(x, y) for x, y in zip(w, b[:3]))
