@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void selftest_division_kernel(uint64_t pairs, 
     unsigned int bad[4] = {0, 0, 0, 0};
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < pairs; i += stride) {
         const uint32_t lo = static_cast<uint32_t>(i), hi = static_cast<uint32_t>(i >> 32);
-        const uint32_t a = mix32(lo ^ seed), b = mix32(a + hi * 0x9e3779b9u + 0x85ebca6bu), c = mix32(b ^ 0xc2b2ae35u);
+        // (the seed enters b non-bijectively: with a = mix32(lo ^ seed) alone two seeds would test permutations of the SAME operand pairs)
+        const uint32_t a = mix32(lo ^ seed), b = mix32(a + mix32(seed + 0x5bd1e995u) * 0x9e3779b9u + hi * 0x85ebca6bu + 0x85ebca6bu), c = mix32(b ^ 0xc2b2ae35u);
         const int cls = static_cast<int>(c & 3u);
         float n, d;
         if (cls == 0) {

@@ -276,8 +276,10 @@ __global__ __launch_bounds__(WPB * SPLIT * 64, WPS) void render_wave_kernel(cons
             plane_coord_recip<AC>(b.zdiff, b.hw, b.hh, __builtin_amdgcn_rcpf(b.hw), __builtin_amdgcn_rcpf(b.hh), ex, ey, crx, cry, crz, crcp,
                                   cx, cy, ix, iy, s);
             const float inf = __builtin_inff();
-            if (!(fabsf(ix) < 1e6f)) ix = inf;  // NaN too (fminf/fmaxf would drop it)
-            if (!(fabsf(iy) < 1e6f)) iy = inf;
+            // |coordinate| < 16384 texels or the strip takes the gather path: the corner chain goes through v_rcp (4e-7 relative: beyond ~45k
+            // texels the error would exceed the box slack of 1/64 texel), and the box origin offset is formed in 32 bits.  NaN too.
+            if (!(fabsf(ix) < 16384.0f)) ix = inf;
+            if (!(fabsf(iy) < 16384.0f)) iy = inf;
             float mnx = ix, mxx = ix, mny = iy, mxy = iy;
 #pragma unroll
             for (int o = 1; o < 4; o <<= 1) {

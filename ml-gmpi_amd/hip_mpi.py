@@ -59,7 +59,7 @@ class MPI(nn.Module):
       strict_order   one rounding per reference op also in the blend (bit-identical to the oracle)
       range_check    "touched" (alpha/rgba range asserted on the texels the render samples, free), "full" (extra
                      exhaustive pass = the reference's min/max over the whole volume, mpi.py:185-187 /
-                     mpi_renderer.py:447-449), "off"; None = `MPI.DEFAULT_RANGE_CHECK` ("touched"; `install()` sets
+                     mpi_renderer.py:447-449), "off"; None = the class's `DEFAULT_RANGE_CHECK` ("touched"; `install()` swaps in subclasses that set
                      it to "full" so that a swapped-in module asserts exactly what the reference asserts).
                      Both modes test all four channels: the reference's `MPI.check_shapes` tests alpha only, but
                      its only caller (`MPIRenderer.render`) has asserted the whole rgba tensor just before.
@@ -73,7 +73,7 @@ class MPI(nn.Module):
         super().__init__()
         self._align_corners = align_corners
         if range_check is None:
-            range_check = MPI.DEFAULT_RANGE_CHECK
+            range_check = type(self).DEFAULT_RANGE_CHECK   # (a class attribute: `install()` swaps in a subclass that overrides it)
         assert variant in _lib.VARIANTS, variant
         assert range_check in ("touched", "full", "off"), range_check
         assert on_out_of_plane in ("exit", "raise"), on_out_of_plane

@@ -22,8 +22,18 @@ def install(patch_mpi: bool = True, patch_renderer: bool = True, patch_light: bo
     from .renderer import MPIRenderer
 
     assert range_check in ("full", "touched", "off"), range_check
-    _SAVED.setdefault(("ml_gmpi_amd", "DEFAULT_RANGE_CHECK"), MPI.DEFAULT_RANGE_CHECK)
-    MPI.DEFAULT_RANGE_CHECK = range_check
+    # What the reference's modules get are SUBCLASSES that carry the default: `ml_gmpi_amd.MPI` / `MPIRenderer` themselves -- and every
+    # instance a direct user of this package builds, before or after install() -- keep "touched" (no process-global state).
+    base_mpi, base_renderer = MPI, MPIRenderer
+
+    class MPI(base_mpi):  # noqa: F811  (same name: reprs and pickles of the swapped-in class read like the reference's)
+        DEFAULT_RANGE_CHECK = range_check
+
+    class MPIRenderer(base_renderer):  # noqa: F811
+        def __init__(self, **kw):
+            kw.setdefault("range_check", range_check)
+            super().__init__(**kw)
+
     core_mpi = importlib.import_module("gmpi.core.mpi")
     core_renderer = importlib.import_module("gmpi.core.mpi_renderer")
     if patch_mpi:
@@ -48,9 +58,6 @@ def install(patch_mpi: bool = True, patch_renderer: bool = True, patch_light: bo
 
 def uninstall() -> None:
     for (mod, name), obj in list(_SAVED.items()):
-        if name == "DEFAULT_RANGE_CHECK":
-            from .hip_mpi import MPI
-            MPI.DEFAULT_RANGE_CHECK = obj
-        elif mod in sys.modules:
+        if mod in sys.modules:
             setattr(sys.modules[mod], name, obj)
     _SAVED.clear()

@@ -20,10 +20,11 @@ def test_install_patches_the_reference_modules_and_uninstall_restores():
         ml_gmpi_amd.install()
         import gmpi.core.mpi as m
         import gmpi.core.mpi_renderer as mr
-        assert m.MPI is ml_gmpi_amd.MPI and mr.MPI is ml_gmpi_amd.MPI and mr.MPIRenderer is ml_gmpi_amd.MPIRenderer
+        assert issubclass(m.MPI, ml_gmpi_amd.MPI) and mr.MPI is m.MPI and issubclass(mr.MPIRenderer, ml_gmpi_amd.MPIRenderer)
+        assert m.MPI.DEFAULT_RANGE_CHECK == "full" and ml_gmpi_amd.MPI.DEFAULT_RANGE_CHECK == "touched"   # no process-global default
         # the way render_video.py binds the name (`from gmpi.core.mpi_renderer import MPIRenderer`) after install()
         from gmpi.core.mpi_renderer import MPIRenderer
-        assert MPIRenderer is ml_gmpi_amd.MPIRenderer
+        assert issubclass(MPIRenderer, ml_gmpi_amd.MPIRenderer)
         import sys
         if "gmpi.core.light_renderer" in sys.modules:   # importable only where torchvision (or a stand-in) is present
             assert sys.modules["gmpi.core.light_renderer"].LightRenderer is ml_gmpi_amd.LightRenderer
@@ -179,7 +180,7 @@ def test_reference_generate_img_drives_the_installed_renderer(monkeypatch):
     try:
         ml_gmpi_amd.install()
         rv = importlib.import_module("gmpi.eval.vis.render_video")   # binds `from gmpi.core.mpi_renderer import MPIRenderer` AFTER install()
-        assert rv.MPIRenderer is ml_gmpi_amd.MPIRenderer
+        assert issubclass(rv.MPIRenderer, ml_gmpi_amd.MPIRenderer)
         kw = dict(ref_import.PRESETS["FFHQ"])
         kw.update(n_mpi_planes=D, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse",
                   cam_sample_method="truncated_gaussian", mpi_align_corners=True, use_xyz_ztype="depth", use_normalized_xyz=False,
