@@ -44,7 +44,12 @@ enum {
                                             variant is gmpi_rgba_range_check_launch                   */
     GMPI_FLAG_STRICT_ORDER = 1 << 4,     /* one rounding per reference op everywhere (bit-identical to
                                             oracle/mpi_oracle.c); default lets the blend use FMA       */
-    GMPI_FLAG_ALL = (1 << 5) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
+    GMPI_FLAG_HINT_FRONTAL = 1 << 5,     /* advisory: every view's camera axis (z_dir) is within 0.2 rad of the MPI normal (0,0,1).
+                                            Only GMPI_VARIANT_AUTO reads it, and only to choose between kernels that render the
+                                            same pixels: the strip kernel's narrow boxes win on small frontal launches, the tile
+                                            kernel's shared boxes on tilted ones (profiles/r03_pose_sweep.txt).  Results never
+                                            depend on it; without it AUTO assumes a tilted camera.                              */
+    GMPI_FLAG_ALL = (1 << 6) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
 };
 
 /* bits of status[0] (OR-accumulated across launches until the caller clears the word) */

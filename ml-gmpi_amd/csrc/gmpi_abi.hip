@@ -292,9 +292,13 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         const int64_t strips = static_cast<int64_t>(p.N) * ((p.W + 31) / 32) * ((p.H + 7) / 8);
         const bool strict = (p.flags & GMPI_FLAG_STRICT_ORDER) != 0;
         const bool lds_ok = lds_variant_supports(p, params->rgba_dtype), wave_ok = wave_variant_supports(p, params->rgba_dtype);
+        // 16-bit volumes between 513 and 2048 strips: the strip kernel wins by 4-7 % under a frontal camera, the tile kernel by 3-10 % (and
+        // more above 1024 strips) from 0.3 rad of yaw on (profiles/r03_pose_sweep.txt) -- the caller's GMPI_FLAG_HINT_FRONTAL decides;
+        // without it: tilted.
+        const bool frontal = (p.flags & GMPI_FLAG_HINT_FRONTAL) != 0;
         const bool small = strict ? (pixels <= (int64_t(1) << 19) && pixels > (int64_t(1) << 18))
                          : params->rgba_dtype == GMPI_DTYPE_F32 ? (strips <= 512 || (strips > 1536 && strips <= 2048))
-                                                                : strips <= 1024;
+                                                                : (strips <= 512 || (strips <= 2048 && frontal));
         variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
         // Large launches over bf16 volumes, when the caller lends a workspace: the band kernel (256 x 8 pixel bands, LDS-DMA; 0.87 ms on
         // BASELINE config 3 where the tile kernel takes 1.02) -- for the views it can stage.  Whether a view's texel boxes fit the band

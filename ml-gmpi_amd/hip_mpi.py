@@ -129,8 +129,9 @@ class MPI(nn.Module):
                      view_to_mpi: Optional[torch.Tensor] = None, check_last_plane: bool = False,
                      out_pm1: bool = False, want_transmittance: bool = False, c2w_mat=None, sphere_c=None,
                      status: Optional[torch.Tensor] = None, defer_status: bool = False, out: Optional[dict] = None,
-                     _in_autograd_fn: bool = False):
-        """Renders N views in one launch.
+                     _in_autograd_fn: bool = False, frontal_hint: bool = False):
+        """Renders N views in one launch.  `frontal_hint`: the caller knows every camera axis to lie within 0.2 rad of the MPI normal
+        (GMPI_FLAG_HINT_FRONTAL: advisory, only the kernel choice of small launches depends on it, never a result).
 
         rgba [M,D,4,Ht,Wt] (f32/bf16/f16, any outer strides, innermost contiguous), dhw [M,D,3],
         ray_dir [N,3,H,W], eye_pos [N,3], z_dir [N,3].  View n samples MPI `view_to_mpi[n]`; without it,
@@ -208,6 +209,8 @@ class MPI(nn.Module):
             flags |= _lib.FLAG_CHECK_RANGE
         if self.strict_order:
             flags |= _lib.FLAG_STRICT_ORDER
+        if frontal_hint:
+            flags |= _lib.FLAG_HINT_FRONTAL
 
         p = _lib.GmpiRenderParams()
         p.struct_size = ctypes.sizeof(_lib.GmpiRenderParams)

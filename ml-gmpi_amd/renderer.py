@@ -25,6 +25,7 @@ from .poses import gen_sphere_path, gen_sphere_paths_ahead, host_math
 logger = logging.getLogger("ml_gmpi_amd")
 
 EPS = 1e-6
+_COS_FRONTAL = 0.98006658  # cos(0.2 rad): GMPI_FLAG_HINT_FRONTAL (include/gmpi_render.h)
 
 # Renderer kwargs of the reference's dataset presets (gmpi/curriculums.py:109-116,133-140,171-178;
 # configs/gmpi.yml:74-110) as gmpi/eval/vis/render_video.py:168-189 assembles them.
@@ -90,6 +91,7 @@ class MPIRenderer:
         self._dhw_dev = None
         self._spec = None            # look-ahead pose queue (see _draw_poses)
         self._ray_bufs = {}          # render()'s own ray buffers (see _generate_rays_hip)
+        self._frontal = False        # GMPI_FLAG_HINT_FRONTAL of the poses last drawn
         self._last_pose_key = None
         self.compute_mpi_spatial_volume()
         self.use_xyz_ztype = use_xyz_ztype
@@ -246,7 +248,8 @@ class MPIRenderer:
         with host_math():
             c2w_dev = torch.FloatTensor(c2w).to(self.device)                       # one host-to-device copy for all calls
             angles_dev = torch.cat([pitches, yaws], -1).to(self.device)           # (render()'s cam_angles)
-        self._spec = dict(key=key, n=n_calls, idx=0, states=states, yaws=yaws, pitches=pitches, c2w=c2w_dev, angles=angles_dev)
+        frontal = [bool(c2w[j, :, 2, 2].min() >= _COS_FRONTAL) for j in range(n_calls)]   # z_dir = third column of c2w
+        self._spec = dict(key=key, n=n_calls, idx=0, states=states, yaws=yaws, pitches=pitches, c2w=c2w_dev, angles=angles_dev, frontal=frontal)
 
     def _take_look_ahead(self, key):
         sp = self._spec
@@ -258,6 +261,7 @@ class MPIRenderer:
             return None
         sp["idx"] = j + 1
         torch.set_rng_state(sp["states"][j + 1])                                    # as if this call had drawn
+        self._frontal = sp["frontal"][j]
         return sp["yaws"][j], sp["pitches"][j], sp["c2w"][j], sp["angles"][j]
 
     def _draw_poses(self, batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std, random_pose,
@@ -279,6 +283,7 @@ class MPIRenderer:
             yaw_std=horizontal_std, pitch_mean=vertical_mean, pitch_std=vertical_std,
             n_truncated_stds=self.cam_pose_n_truncated_stds, flag_rnd=random_pose,
             sample_method=self.cam_sample_method, given_yaws=given_yaws, given_pitches=given_pitches)
+        self._frontal = bool(np.asarray(c2w)[:, 2, 2].min() >= _COS_FRONTAL) if not isinstance(c2w, torch.Tensor) else False
         batch_tf_c2w = (c2w if isinstance(c2w, torch.Tensor) else torch.FloatTensor(c2w)).to(self.device)
         return yaws, pitches, batch_tf_c2w, None
 
@@ -354,12 +359,13 @@ class MPIRenderer:
         batch_size = n_mpis * views_per_mpi
         if render_h != self.render_h or render_w != self.render_w:
             self.set_cam(self.cam_fov, render_h, render_w)
-        cam_angles = None
+        cam_angles, frontal = None, False
         if given_cam_infos is None and self.ray_backend == "hip":
             # the batched path: poses (from the look-ahead queue when the request repeats), one ray kernel into this renderer's own
             # ray buffers -- no per-view lists, no torch.cat
             yaws, pitches, c2w, cam_angles = self._draw_poses(batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std,
                                                               random_pose, given_yaws, given_pitches)
+            frontal = self._frontal   # (known on the host: the poses were drawn here)
             ray_t, eye_t, zd_t = self._generate_rays_hip(c2w, reuse=True)
         else:
             if given_cam_infos is None:
@@ -383,7 +389,7 @@ class MPIRenderer:
         res = self.mpi.render_views(
             batch_mpi_rgbas, dhw, ray_t, eye_t, zd_t, views_per_mpi=views_per_mpi,
             check_last_plane=assert_not_out_of_last_plane, out_pm1=True, want_transmittance=want_T,
-            c2w_mat=c2w, sphere_c=self.sphere_center, defer_status=defer)
+            c2w_mat=c2w, sphere_c=self.sphere_center, defer_status=defer, frontal_hint=frontal)
         if cam_angles is None:
             cam_angles = torch.cat([pitches, yaws], -1).to(self.device)
         if want_T:

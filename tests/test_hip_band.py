@@ -183,3 +183,18 @@ def test_workspace_contract():
     pf = params("band", d[0].float())
     pf.workspace, pf.workspace_bytes = ws.data_ptr(), need
     assert lib.gmpi_mpi_render_launch(ctypes.byref(pf), None) == E_VARIANT           # fp32 volumes are not the band kernel's
+
+
+def test_frontal_hint_changes_no_result():
+    """GMPI_FLAG_HINT_FRONTAL is advisory: AUTO's choice between the strip and the tile kernel on a small 16-bit launch depends on it, the
+    pixels (strict-order mode: bit for bit) do not -- whether the hint is true or not."""
+    from ml_gmpi_amd import MPI
+    rgba, dhw, ray, eye, zd = _bf16_case(seed=81, B=4, D=6, S=256)   # 1024 strips of 32 x 8 pixels: the launch size the hint decides
+    orc = oracle.render(rgba.float(), dhw, ray, eye, zd)
+    dev = torch.device("cuda:0")
+    mpi = MPI(align_corners=True, variant="auto", strict_order=True, on_out_of_plane="raise")
+    args = [t.to(dev) for t in (rgba, dhw, ray, eye, zd)]
+    with torch.no_grad():
+        for hint in (False, True):
+            out = mpi.render_views(*args, check_last_plane=True, frontal_hint=hint)
+            assert np.array_equal(out["color"].cpu().numpy(), orc["color"]) and np.array_equal(out["depth"].cpu().numpy(), orc["depth"]), hint

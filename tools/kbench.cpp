@@ -93,6 +93,11 @@ int main(int argc, char** argv) {
         if (v.size() > 2 && v.substr(v.size() - 2) == ":s") strict = true, v = v.substr(0, v.size() - 2);
         p.variant = v == "gather" ? 1 : v == "lds" ? 2 : v == "wave" ? 3 : v == "dma" ? 4 : v == "band" ? 5 : 0;
         p.flags = GMPI_FLAG_ALIGN_CORNERS | GMPI_FLAG_OUT_PM1 | GMPI_FLAG_CHECK_LAST_PLANE | GMPI_FLAG_CHECK_RANGE | (strict ? GMPI_FLAG_STRICT_ORDER : 0);
+        {  // the hint a host that knows the poses gives (MPIRenderer.render does): every camera axis within 0.2 rad of the MPI normal
+            bool frontal = true;
+            for (int n = 0; n < N; ++n) frontal = frontal && zd[n * 3 + 2] >= 0.98006658f;  // cos(0.2)
+            if (frontal) p.flags |= GMPI_FLAG_HINT_FRONTAL;
+        }
         CK(hipMemset(d_st, 0, 256)); CK(hipMemset(d_rgb, 0xff, npix * 12)); CK(hipMemset(d_dep, 0xff, npix * 4));
         int rc = launch(&p, nullptr);
         if (rc != 0) { printf("%-8s rc=%d\n", v.c_str(), rc); continue; }

@@ -55,3 +55,14 @@ S, D = 1024, 256
 r.set_cam(r.cam_fov, S, S)
 torch.manual_seed(3)
 dump("c5", r.sample_cam_poses(4, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))
+
+# pose sweep sets: every view at the same yaw, pitch 0 -- 8 views of 256^2 and 2 views of 512^2 per yaw
+kw = dict(PRESETS["FFHQ"])
+kw.update(n_mpi_planes=96, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse", cam_sample_method="truncated_gaussian",
+          mpi_align_corners=True, use_confined_volume=True, device=torch.device("cpu"))
+r = MPIRenderer(**kw)
+for S, n in ((256, 8), (512, 2)):
+    r.set_cam(r.cam_fov, S, S)
+    for yaw in (0.0, 0.3, 0.45, 0.578):
+        gy = torch.full((n, 1), yaw); gp = torch.zeros((n, 1))
+        dump(f"p{S}_y{int(round(yaw * 1000)):03d}", r.sample_cam_poses(n, 0, 0, 0, 0, False, given_yaws=gy, given_pitches=gp))
