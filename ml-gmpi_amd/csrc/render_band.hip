@@ -20,9 +20,9 @@
 // Arithmetic: gmpi_device.hpp (bit-identical to the oracle in strict-order mode).
 #include "gmpi_device.hpp"
 
+#include <algorithm>
 #include <type_traits>
 
-#define GMPI_BAND_ISSUE_FIRST 1
 
 namespace gmpi {
 namespace band {
@@ -96,6 +96,9 @@ __device__ __forceinline__ void dma16x2(uint32_t voff, uint32_t soff1, const u32
                  : "memory", "scc");
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (Measured and dropped, profiles/r03_band_variants.txt: the same rendezvous among the 4 waves of ONE sub-block only -- an LDS counter, arrive =
+//  ds_add by lane 0, wait = poll with s_sleep -- is bit-exact but 7-9 % SLOWER than the workgroup barrier: the sub-blocks drift apart by planes,
+//  their requests no longer form the 528-byte pieces per row the memory side likes, and the polling costs issue slots.)
 // (a d16_hi load zeroes the low half of its destination on gfx950: tools/ubench/r3_probe.hip `sem`)
 template <int O> __device__ __forceinline__ void tap16(uint32_t& t, uint32_t a) {
     asm volatile("ds_read_u16_d16_hi %0, %1 offset:%2" : "=v"(t) : "v"(a), "i"(O));
@@ -146,7 +149,7 @@ __device__ __forceinline__ Shape shape_unpack(uint32_t w) {
     return h;
 }
 template <typename TexT, bool AC>
-__global__ __launch_bounds__(256) void band_table_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
+__global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
                                                          uint4* __restrict__ recs, uint4* __restrict__ pl, uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes;
@@ -409,9 +412,8 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         //      no masks.  The verdict is taken once per band (check_verdict below).
         uint32_t chk_acc = 0;
         auto check_fold = [&](const u32x4& q) {
-            if (BF)
-                asm volatile("v_max3_u16 %0, %0, %1, %1 op_sel:[0,0,1,0]\n\tv_max3_u16 %0, %0, %2, %2 op_sel:[0,0,1,0]\n\t"
-                             "v_max3_u16 %0, %0, %3, %3 op_sel:[0,0,1,0]\n\tv_max3_u16 %0, %0, %4, %4 op_sel:[0,0,1,0]"
+            if (BF)  // two running maxima, one per 16-bit half (v_pk_max_u16: 1.8 ns per wave and SIMD; v_max3_u16 with op_sel measured 3.4 ns)
+                asm volatile("v_pk_max_u16 %0, %0, %1\n\tv_pk_max_u16 %0, %0, %2\n\tv_pk_max_u16 %0, %0, %3\n\tv_pk_max_u16 %0, %0, %4"
                              : "+v"(chk_acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
             else
                 asm volatile("v_max3_u32 %0, %0, %1, %2\n\tv_max3_u32 %0, %0, %3, %4" : "+v"(chk_acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
@@ -495,7 +497,6 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
             u32x4 cq0, cq1, cq2;
             uint32_t g_off;
             const bool three_cur = three;  // set by the issue of this plane, one step ago
-#ifdef GMPI_BAND_ISSUE_FIRST
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g_off) : "v"(a_g));
             if (tt + 1 < D && !abl_noissue) issue(Ln, g_off, ic<1 - U>{});
             GMPI_STAMP(3);
@@ -511,26 +512,6 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                 }
                 GMPI_STAMP(2);
             }
-#else
-            if (check_range) {
-                asm volatile("ds_read_b32 %2, %4\n\tds_read_b128 %0, %3 offset:%5\n\tds_read_b128 %1, %3 offset:%6\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(cq0), "=&v"(cq1), "=&v"(g_off)
-                             : "v"(a_it), "v"(a_g), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                GMPI_STAMP(1);
-                check_fold(cq0), check_fold(cq1);
-                if (three_cur) {  // (the box of THIS plane has a third pass: the rest of the sub-block's buffer -- lanes beyond it re-read its first item)
-                    constexpr int kTail = (kSubBytes - 2 * kPassItems * 16) / 16;
-                    const uint32_t a_t = sub_base + static_cast<uint32_t>(min(fresh_tid() & (kSubLanes - 1), kTail - 1)) * 16u;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq2) : "v"(a_t), "i"(U * kBufBytes + 2 * kPassItems * 16));
-                    check_fold(cq2);
-                }
-                GMPI_STAMP(2);
-            } else {
-                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g_off) : "v"(a_g));
-            }
-            if (tt + 1 < D && !abl_noissue) issue(Ln, g_off, ic<1 - U>{});
-            GMPI_STAMP(3);
-#endif
             const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
             // tap address constant of this plane and buffer (an integer below 2^24, exact in fp32)
             const float2 rg = make_float2(__uint_as_float(rhh_c), static_cast<float>(static_cast<int>(gp_c) + static_cast<int>(tile_base) + U * kBufBytes));
@@ -565,7 +546,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         //      says nothing about the values below it, so such a band re-tests its texels one by one (cold: never for generator output) ----
         if (check_range) {
             constexpr uint32_t kOne = BF ? 0x3f80u : 0x3f800000u, kNegZero = BF ? 0x8000u : 0x80000000u;
-            const uint32_t mx = BF ? (chk_acc & 0xffffu) : chk_acc;
+            const uint32_t mx = BF ? max(chk_acc & 0xffffu, chk_acc >> 16) : chk_acc;
 #ifdef GMPI_TUNE
             if (p.status != nullptr && mx > kOne) { atomicMax(p.status + 1, mx); atomicMax(p.status + 2, static_cast<uint32_t>(band_id)); atomicMax(p.status + 3, static_cast<uint32_t>(tid)); }
 #endif
@@ -667,7 +648,7 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
     uint4* recs = reinterpret_cast<uint4*>(static_cast<unsigned char*>(p.ws) + ws_hdr_bytes(n_bands, p.N) + ws_pl_bytes(p));
     // 1. the geometry table (one workgroup per band; writes every word the render kernel reads but the two planes of padding, whose content
     //    is never used)
-    const dim3 tgrid(static_cast<unsigned>(n_bands)), tblock(256);
+    const dim3 tgrid(static_cast<unsigned>(n_bands)), tblock(static_cast<unsigned>(std::min(1024, (p.D * NSB + 63) / 64 * 64)));  // one record per thread up to 256 planes
     if (acf) hipLaunchKernelGGL((band_table_kernel<TexT, true>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr);
     else hipLaunchKernelGGL((band_table_kernel<TexT, false>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr);
     // 2. the render

@@ -40,6 +40,8 @@
 // of tiles).  Algorithmic bytes: 16 B (fp32) / 8 B (bf16) per pixel*plane + 28-32 B per pixel.
 #include "gmpi_device.hpp"
 
+#include <algorithm>
+
 #include <type_traits>
 
 namespace gmpi {
@@ -140,9 +142,11 @@ __device__ __forceinline__ bool quad_out_of_unit(const float4& q) {
 //   (fp32: 4 dword loads), one 16-byte store.  A pixel's 16 taps are two ds_read2_b64 (16-bit: 32 bytes instead of 64,
 //   unpacked to fp32 in registers) or four ds_read_b128 (fp32: 8 lanes per LDS pass, so the bank wrap of a stretched
 //   row only bites when a texel is skipped inside 8 pixels).
+// The body of one workgroup's tile, as a function of the (virtual) block index: the kernels below call it once (render_lds_kernel) or in a
+// loop over a small grid (render_lds_gated_kernel).
 template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF, int LAYOUT>
-__global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y,
-                                                               const int n_tiles) {
+__device__ __forceinline__ void render_lds_tile(const KParams& p, const int tiles_x, const int tiles_y, const int n_tiles, const unsigned vblock,
+                                                const unsigned char* view_in = nullptr) {  // view_in: the gate, per view, already in LDS
     using Q = Quad<TexT>;
     constexpr int LPR = LAYOUT == 1 ? 1 : 4;
     constexpr int kTexelBytes = 4 * static_cast<int>(sizeof(TexT));  // interleaved layout: RGBA of one texel
@@ -165,20 +169,20 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     //      neighbouring tiles (shared halo texels) meet in one L2 ------------------------------------------
     const int tiles_per_view = tiles_x * tiles_y;
     const int per_xcd = (n_tiles + 7) / 8;
-    int tile_id = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    if (blockIdx.x >= static_cast<unsigned>(per_xcd * 8)) tile_id = n_tiles;
+    int tile_id = (vblock % 8) * per_xcd + vblock / 8;
+    if (vblock >= static_cast<unsigned>(per_xcd * 8)) tile_id = n_tiles;
     // Per-group order (every view's tiles spread over all XCDs, the XCDs walk the views together):
     //  * a gated launch -- AUTO's fallback for the views the band kernel leaves -- renders only some of the views: with one run of all tiles
     //    per XCD a single view would run on the one or two XCDs that hold it;
     //  * fp32 volumes: measured 1.5 % (config 3 shape) to 3.7 % (config 5) faster than one run per XCD, 16-bit volumes 1 % slower
     //    (profiles/r03_xcd_order.txt) -- so 16-bit volumes keep the run per XCD.
     if (p.gate != nullptr || sizeof(TexT) == 4)
-        tile_id = xcd_item_per_group(blockIdx.x, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
+        tile_id = xcd_item_per_group(vblock, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
 #ifdef GMPI_TUNE  // (experiment: flag bit 19 flips the order)
     if (p.flags & (1u << 19)) {
-        tile_id = (p.gate != nullptr || sizeof(TexT) == 4) ? (blockIdx.x % 8) * per_xcd + blockIdx.x / 8
-                                                           : xcd_item_per_group(blockIdx.x, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
-        if (blockIdx.x >= static_cast<unsigned>(per_xcd * 8) && (p.gate != nullptr || sizeof(TexT) == 4)) tile_id = n_tiles;
+        tile_id = (p.gate != nullptr || sizeof(TexT) == 4) ? (vblock % 8) * per_xcd + vblock / 8
+                                                           : xcd_item_per_group(vblock, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
+        if (vblock >= static_cast<unsigned>(per_xcd * 8) && (p.gate != nullptr || sizeof(TexT) == 4)) tile_id = n_tiles;
     }
 #endif
     if (tile_id >= n_tiles) return;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
         n = tile_id / tiles_per_view;
         trem = tile_id - n * tiles_per_view;
     }
-    if (view_gated_out(p, n)) return;  // (AUTO: this view is the band kernel's)
+    if (view_in != nullptr ? !view_in[n] : view_gated_out(p, n)) return;  // (AUTO: this view is the band kernel's)
     const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
 
     const int tid = threadIdx.x;
@@ -621,6 +625,36 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
     report_status(p.status, bad);
 }
 
+
+template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF, int LAYOUT>
+__global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, const int tiles_x, const int tiles_y, const int n_tiles) {
+    render_lds_tile<TexT, AC, STRICT, TW, MINW, PF, LAYOUT>(p, tiles_x, tiles_y, n_tiles, blockIdx.x);
+}
+
+// AUTO's fallback launch for the views the band kernel leaves (KParams::gate): usually NO view is left, and a grid of one workgroup per
+// tile of every view that only exits costs 17 us for BASELINE config 3 (8192 workgroups: the dispatch rate).  So the gated launch has a
+// fixed, small grid whose workgroups walk the virtual block indices with a stride: 2 us when there is nothing to do.
+constexpr unsigned kGatedGrid = 1024;
+template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF, int LAYOUT>
+__global__ __launch_bounds__(kNT, MINW) void render_lds_gated_kernel(const KParams p, const int tiles_x, const int tiles_y, const int n_tiles,
+                                                                     const unsigned n_vblocks) {
+    // the gate words once per workgroup (a global load per tile would cost more than the dispatch it saves); nothing to do: exit
+    __shared__ unsigned char view_in[kNT];
+    const bool cached = p.N <= kNT;
+    if (cached) {
+        bool mine = false;
+        if (static_cast<int>(threadIdx.x) < p.N) {
+            mine = !view_gated_out(p, static_cast<int>(threadIdx.x));
+            view_in[threadIdx.x] = mine ? 1 : 0;
+        }
+        if (!__syncthreads_or(mine ? 1 : 0)) return;
+    }
+    for (unsigned vb = blockIdx.x; vb < n_vblocks; vb += gridDim.x) {
+        render_lds_tile<TexT, AC, STRICT, TW, MINW, PF, LAYOUT>(p, tiles_x, tiles_y, n_tiles, vb, cached ? view_in : nullptr);
+        __syncthreads();  // the next tile reuses the staging buffers and the table
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 static int elem_size(int dtype) { return dtype == 0 ? 4 : 2; }
 
@@ -656,6 +690,14 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
                                               : static_cast<unsigned>(((n_tiles + 7) / 8) * 8);
     const dim3 grid(grid_x), block(kNT);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
+    if (p.gate != nullptr) {
+        const dim3 ggrid(std::min(grid_x, kGatedGrid));
+        if (ac && strict) hipLaunchKernelGGL((render_lds_gated_kernel<TexT, true, true, TW, MINW, PF, LAYOUT>), ggrid, block, 0, stream, p, tiles_x, tiles_y, n_tiles, grid_x);
+        else if (ac) hipLaunchKernelGGL((render_lds_gated_kernel<TexT, true, false, TW, MINW, PF, LAYOUT>), ggrid, block, 0, stream, p, tiles_x, tiles_y, n_tiles, grid_x);
+        else if (strict) hipLaunchKernelGGL((render_lds_gated_kernel<TexT, false, true, TW, MINW, PF, LAYOUT>), ggrid, block, 0, stream, p, tiles_x, tiles_y, n_tiles, grid_x);
+        else hipLaunchKernelGGL((render_lds_gated_kernel<TexT, false, false, TW, MINW, PF, LAYOUT>), ggrid, block, 0, stream, p, tiles_x, tiles_y, n_tiles, grid_x);
+        return hipGetLastError();
+    }
     if (ac && strict) hipLaunchKernelGGL((render_lds_kernel<TexT, true, true, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
     else if (ac) hipLaunchKernelGGL((render_lds_kernel<TexT, true, false, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);
     else if (strict) hipLaunchKernelGGL((render_lds_kernel<TexT, false, true, TW, MINW, PF, LAYOUT>), grid, block, 0, stream, p, tiles_x, tiles_y, n_tiles);

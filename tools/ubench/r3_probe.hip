@@ -96,6 +96,11 @@ __global__ void valu_kernel(float* out, int iters) {
         if (MODE == 12) { ASM8("v_mul_f32 %0, %1, %8\n v_mul_f32 %1, %2, %8\n v_mul_f32 %2, %3, %8\n v_mul_f32 %3, %4, %8\n v_mul_f32 %4, %5, %8\n v_mul_f32 %5, %6, %8\n v_mul_f32 %6, %7, %8\n v_mul_f32 %7, %0, %8\n") }
         if (MODE == 13) { ASM8("v_and_b32 %0, 0xffff0000, %1\n v_and_b32 %1, 0xffff0000, %2\n v_and_b32 %2, 0xffff0000, %3\n v_and_b32 %3, 0xffff0000, %4\n v_and_b32 %4, 0xffff0000, %5\n v_and_b32 %5, 0xffff0000, %6\n v_and_b32 %6, 0xffff0000, %7\n v_and_b32 %7, 0xffff0000, %0\n") }
         if (MODE == 14) { ASM8("v_max_f32 %0, %1, %8\n v_max_f32 %1, %2, %8\n v_max_f32 %2, %3, %8\n v_max_f32 %3, %4, %8\n v_max_f32 %4, %5, %8\n v_max_f32 %5, %6, %8\n v_max_f32 %6, %7, %8\n v_max_f32 %7, %0, %8\n") }
+        if (MODE == 16) { ASM8("v_max3_u16 %0, %0, %1, %1 op_sel:[0,0,1,0]\n v_max3_u16 %1, %1, %2, %2 op_sel:[0,0,1,0]\n v_max3_u16 %2, %2, %3, %3 op_sel:[0,0,1,0]\n v_max3_u16 %3, %3, %4, %4 op_sel:[0,0,1,0]\n v_max3_u16 %4, %4, %5, %5 op_sel:[0,0,1,0]\n v_max3_u16 %5, %5, %6, %6 op_sel:[0,0,1,0]\n v_max3_u16 %6, %6, %7, %7 op_sel:[0,0,1,0]\n v_max3_u16 %7, %7, %0, %0 op_sel:[0,0,1,0]\n") }
+        if (MODE == 17) { ASM8("v_pk_max_u16 %0, %0, %1\n v_pk_max_u16 %1, %1, %2\n v_pk_max_u16 %2, %2, %3\n v_pk_max_u16 %3, %3, %4\n v_pk_max_u16 %4, %4, %5\n v_pk_max_u16 %5, %5, %6\n v_pk_max_u16 %6, %6, %7\n v_pk_max_u16 %7, %7, %0\n") }
+        if (MODE == 18) { ASM8("v_max3_u32 %0, %0, %1, %8\n v_max3_u32 %1, %1, %2, %8\n v_max3_u32 %2, %2, %3, %8\n v_max3_u32 %3, %3, %4, %8\n v_max3_u32 %4, %4, %5, %8\n v_max3_u32 %5, %5, %6, %8\n v_max3_u32 %6, %6, %7, %8\n v_max3_u32 %7, %7, %0, %8\n") }
+        if (MODE == 19) { ASM8("v_max_u32 %0, %0, %1\n v_max_u32 %1, %1, %2\n v_max_u32 %2, %2, %3\n v_max_u32 %3, %3, %4\n v_max_u32 %4, %4, %5\n v_max_u32 %5, %5, %6\n v_max_u32 %6, %6, %7\n v_max_u32 %7, %7, %0\n") }
+        if (MODE == 20) { ASM8("v_or_b32 %0, %0, %1\n v_or_b32 %1, %1, %2\n v_or_b32 %2, %2, %3\n v_or_b32 %3, %3, %4\n v_or_b32 %4, %4, %5\n v_or_b32 %5, %5, %6\n v_or_b32 %6, %6, %7\n v_or_b32 %7, %7, %0\n") }
         if (MODE == 15) { ASM8("v_cvt_f32_u32 %0, %1\n v_cvt_f32_u32 %1, %2\n v_cvt_f32_u32 %2, %3\n v_cvt_f32_u32 %3, %4\n v_cvt_f32_u32 %4, %5\n v_cvt_f32_u32 %5, %6\n v_cvt_f32_u32 %6, %7\n v_cvt_f32_u32 %7, %0\n") }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
@@ -246,7 +251,11 @@ int main(int argc, char** argv) {
     if (!strcmp(what, "sem")) { run_sem(); return 0; }
     ramp();
     if (!strcmp(what, "valu")) {
-        for (int w : {4, 8}) {
+        if (argc > 2) {  // the candidates of the band kernel's range-check fold
+            run_valu<16>("v_max3_u16 op_sel", 4); run_valu<17>("v_pk_max_u16", 4); run_valu<18>("v_max3_u32", 4); run_valu<19>("v_max_u32", 4); run_valu<20>("v_or_b32", 4); run_valu<0>("v_fma_f32", 4);
+            return 0;
+        }
+        for (int w : {4}) {
             run_valu<0>("v_fma_f32", w); run_valu<12>("v_mul_f32", w); run_valu<5>("v_sub_f32", w); run_valu<14>("v_max_f32", w); run_valu<1>("v_floor_f32", w); run_valu<2>("v_fract_f32", w);
             run_valu<3>("v_cvt_u32_f32", w); run_valu<15>("v_cvt_f32_u32", w); run_valu<4>("v_cvt_flr_i32_f32", w); run_valu<11>("v_med3_f32", w); run_valu<6>("v_cndmask_b32", w);
             run_valu<7>("v_cmp_lt_u32", w); run_valu<8>("v_mov_b32", w); run_valu<13>("v_and_b32", w); run_valu<9>("v_lshl_add_u32", w); run_valu<10>("v_mad_u32_u24", w);
