@@ -18,12 +18,13 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 from ml_gmpi_amd.renderer import MPIRenderer, PRESETS
 t0 = time.time()
 worst = dict(color=0.0, depth=0.0, T=0.0)
+n_runs = 0
 for i in range(n_cases):
     big = rng.random() < 0.15
     H, W = (int(rng.integers(200, 700)), int(rng.integers(200, 700))) if big else (int(rng.integers(4, 200)), int(rng.integers(4, 200)))
     Ht, Wt = 8 * int(rng.integers(1, 80 if big else 30)), 8 * int(rng.integers(1, 80 if big else 30))
     D = int(rng.integers(1, 40 if big else 130))
-    B = int(rng.integers(1, 4))
+    B = int(rng.integers(1, 4)) if not (big and rng.random() < 0.3) else int(rng.integers(4, 9))   # (many views: AUTO's band + gated tile launch)
     preset = ["FFHQ", "AFHQCat", "MetFaces"][int(rng.integers(0, 3))]
     ac = bool(rng.integers(0, 2))
     kw = dict(PRESETS[preset])
@@ -50,7 +51,9 @@ for i in range(n_cases):
     ray = torch.cat(cam[3])[:, :, :H, :W].contiguous()
     eye, zd = torch.cat(cam[4]), torch.cat(cam[5])
     orc = oracle.render(vol.float(), dhw, ray, eye, zd, align_corners=ac, threads=True)
-    for variant in ("gather", "lds", "wave", "auto"):
+    variants = ("gather", "lds", "wave", "auto") + (("dma", "band") if dtype == torch.bfloat16 else ())
+    n_runs += len(variants)
+    for variant in variants:
         out = hip_render(vol, dhw, ray, eye, zd, ac=ac, variant=variant, strict=True, check_last=False)
         for k in ("color", "depth", "T"):
             if not np.array_equal(out[k], orc[k]):
@@ -64,4 +67,5 @@ for i in range(n_cases):
             if not err <= tol:
                 print("DEFAULT-MODE MISMATCH", i, dict(H=H, W=W, Ht=Ht, Wt=Wt, D=D, B=B, preset=preset, ac=ac, dtype=str(dtype), mode=mode), variant, k, err)
                 sys.exit(1)
-print(f"fuzz ok: {n_cases} cases x 4 variants x 2 modes in {time.time() - t0:.0f} s; worst default-mode error {worst}")
+print(f"fuzz ok: {n_cases} cases, {n_runs} (case, variant) pairs x 2 modes (gather / lds / wave / auto, + dma / band on bf16 volumes) in {time.time() - t0:.0f} s; "
+      f"worst default-mode error {worst}")
