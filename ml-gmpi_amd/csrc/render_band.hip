@@ -177,11 +177,16 @@ __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const
         const int bx0p = min(sx0 + b * SBW, W - 1), bx1p = min(sx0 + b * SBW + SBW - 1, W - 1);
         float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
         bool finite = true;
+        // (corner coordinates through v_rcp_f32 -- 4e-7 relative, i.e. below 0.007 texel inside the 16384-texel limit -- as in the strip
+        //  kernel's box_of: the box only has to CONTAIN the taps, which the slack of 1/64 texel on every side covers; the pixels' own
+        //  coordinates in the render kernel go through the exact chain)
+        const float rw_a = __builtin_amdgcn_rcpf(hw), rh_a = __builtin_amdgcn_rcpf(hh);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {  // the warp is a homography: the box of the sub-block's taps is spanned by its 4 corner pixels
             const int64_t q = static_cast<int64_t>((c & 2) ? by1p : by0p) * W + ((c & 1) ? bx1p : bx0p);
-            float ix, iy, sc, u, v;
-            plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, sc, u, v);
+            float ix, iy, sc;
+            const float crz = rdv[2 * HW + q];
+            plane_coord_recip<AC>(zdiff, hw, hh, rw_a, rh_a, ex, ey, rdv[q], rdv[HW + q], crz, __builtin_amdgcn_rcpf(crz), cx, cy, ix, iy, sc);
             finite = finite && (fabsf(ix) < kCoordLimit) && (fabsf(iy) < kCoordLimit);  // false for NaN too
             mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
         }
@@ -226,7 +231,7 @@ template <typename TexT, bool AC, bool STRICT, bool CHECK>
 __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
                                                          const uint4* __restrict__ recs, const uint4* __restrict__ pl, const uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
-    constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kNP = G::kNP;
+    constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kNP = G::kNP;
     constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
     constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
     constexpr bool BF = kES == 2;
