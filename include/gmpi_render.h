@@ -68,7 +68,7 @@ enum {
     GMPI_VARIANT_LDS = 2,    /* pixel tiles, texel boxes staged through LDS with 16-byte row loads      */
     GMPI_VARIANT_WAVE = 3,   /* wave-private 32x8 pixel strips, whole RGBA texels (fp32 / fp16) in LDS  */
     GMPI_VARIANT_DMA = 4,    /* pixel tiles, raw texel boxes moved HBM -> LDS by the LDS-DMA path (bf16 volumes)        */
-    GMPI_VARIANT_BAND = 5    /* 256 x 8 pixel bands, 2 pixels per thread, LDS-DMA loader (bf16 volumes; needs the workspace) */
+    GMPI_VARIANT_BAND = 5    /* 256 x 8 (bf16) / 128 x 8 (fp32) pixel bands, LDS-DMA loader; needs the workspace               */
 };
 
 enum {
@@ -129,7 +129,7 @@ typedef struct GmpiRenderParams {
 uint64_t gmpi_render_workspace_bytes(const GmpiRenderParams *params);
 
 /* Enqueue the fused render on `stream`.  Replaces MPI.forward (mpi.py:308-436).
- * GMPI_VARIANT_AUTO picks the kernel from the launch shape; for large launches over bf16 volumes with a workspace it enqueues
+ * GMPI_VARIANT_AUTO picks the kernel from the launch shape; for large launches over bf16 / fp32 volumes with a workspace it enqueues
  * the band kernel and the tile kernel together and shares out the views on the device: the band kernel takes every view whose
  * texel boxes fit its staging buffers (mildly tilted cameras), the tile kernel the others.  An explicit variant that cannot
  * take the parameters returns GMPI_E_VARIANT. */
@@ -247,7 +247,7 @@ int gmpi_selftest_division_launch(uint64_t pairs, uint32_t seed, uint64_t *misma
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
  * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height, 6 whether
  * GMPI_VARIANT_WAVE is built in, 7 GMPI_VARIANT_DMA, 8 GMPI_VARIANT_BAND, 9 the number of 256 x 8 pixel bands from which
- * GMPI_VARIANT_AUTO uses the band kernel.  Unknown -> -1.                                        */
+ * GMPI_VARIANT_AUTO uses the band kernel on bf16 volumes, 10 the number of 128 x 8 pixel bands on fp32 volumes.  Unknown -> -1.                                        */
 int gmpi_query(int32_t what);
 
 const char *gmpi_version_string(void);

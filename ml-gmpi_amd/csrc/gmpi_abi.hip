@@ -21,8 +21,9 @@ hipError_t launch_dma(const KParams& p, int dtype, int tune, hipStream_t stream)
 bool dma_variant_supports(const KParams& p, int dtype);                     // render_dma.hip
 hipError_t launch_band(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_band.hip
 bool band_variant_supports(const KParams& p, int dtype);                    // render_band.hip
-uint64_t band_workspace_bytes(const KParams& p);                            // render_band.hip
-uint32_t* band_gate_words(const KParams& p);                                // render_band.hip
+uint64_t band_workspace_bytes(const KParams& p, int dtype);                 // render_band.hip
+uint32_t* band_gate_words(const KParams& p, int dtype);                     // render_band.hip
+int band_pixels_wide(int dtype);                                            // render_band.hip
 
 // ---- min/max of the normalised grid on the last plane (mpi.py:103-109 diagnostics) --------------
 template <bool AC>
@@ -263,7 +264,15 @@ static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, 
     return GMPI_OK;
 }
 
-constexpr int64_t kAutoBandMin = 512;  // bands (of 256 x 8 pixels) from which AUTO takes the band kernel: two workgroups on every CU
+constexpr int64_t kAutoBandMin = 512;      // bf16: bands (of 256 x 8 pixels) from which AUTO takes the band kernel: two workgroups on every CU
+constexpr int64_t kAutoBandMinF32 = 1024;  // fp32: bands of 128 x 8 pixels (at 512 -- config 2 -- the strip kernel is as fast: profiles/r03_band_variants.txt)
+
+// does GMPI_VARIANT_AUTO consider the band kernel for this launch (given a workspace and the band kernel's alignment preconditions)?
+static bool auto_takes_band(const KParams& p, int dtype) {
+    if (dtype != GMPI_DTYPE_BF16 && dtype != GMPI_DTYPE_F32) return false;
+    const int bw = band_pixels_wide(dtype);
+    return static_cast<int64_t>(p.N) * ((p.W + bw - 1) / bw) * ((p.H + 7) / 8) >= (dtype == GMPI_DTYPE_BF16 ? kAutoBandMin : kAutoBandMinF32);
+}
 
 static int hip_rc(hipError_t e) { return e == hipSuccess ? GMPI_OK : GMPI_E_LAUNCH - static_cast<int>(e); }
 
@@ -300,18 +309,16 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
                          : params->rgba_dtype == GMPI_DTYPE_F32 ? (strips <= 512 || (strips > 1536 && strips <= 2048))
                                                                 : (strips <= 512 || (strips <= 2048 && frontal));
         variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
-        // Large launches over bf16 volumes, when the caller lends a workspace: the band kernel (256 x 8 pixel bands, LDS-DMA; 0.87 ms on
-        // BASELINE config 3 where the tile kernel takes 1.02) -- for the views it can stage.  Whether a view's texel boxes fit the band
+        // Large launches over bf16 / fp32 volumes, when the caller lends a workspace: the band kernel (256 x 8 / 128 x 8 pixel bands, LDS-DMA;
+        // 0.81 ms on BASELINE config 3 where the tile kernel takes 1.02, 1.21 against 1.33 with an fp32 volume) -- for the views it can stage.  Whether a view's texel boxes fit the band
         // kernel's buffers depends on the camera (tilt shears the boxes) and is only known on the device, so AUTO launches BOTH kernels and
         // lets the band kernel's table kernel share out the views through a gate word per view (KParams::gate): views with a box that does
         // not fit fall to the tile kernel, the others' tile workgroups exit at once (an empty second launch costs a few microseconds).
-        const int64_t bands = static_cast<int64_t>(p.N) * ((p.W + 255) / 256) * ((p.H + 7) / 8);
-        if (variant == GMPI_VARIANT_LDS && params->rgba_dtype == GMPI_DTYPE_BF16 && bands >= kAutoBandMin &&
-            band_variant_supports(p, params->rgba_dtype)) {
+        if (variant == GMPI_VARIANT_LDS && auto_takes_band(p, params->rgba_dtype) && band_variant_supports(p, params->rgba_dtype)) {
             static std::atomic<uint32_t> gate_counter{0x6d2b79f5u};
             uint32_t gen = gate_counter.fetch_add(1u, std::memory_order_relaxed);
             KParams pb = p;
-            pb.gate = band_gate_words(p), pb.gate_gen = gen, pb.gate_sense = 0u;
+            pb.gate = band_gate_words(p, params->rgba_dtype), pb.gate_gen = gen, pb.gate_sense = 0u;
             const hipError_t e = launch_band(pb, params->rgba_dtype, 0, st);
             if (e != hipSuccess) return hip_rc(e);
             pb.gate_sense = 1u;
@@ -349,9 +356,9 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
 uint64_t gmpi_render_workspace_bytes(const GmpiRenderParams* params) {
     KParams p;
     if (to_kparams(params, p, true) != GMPI_OK || p.N == 0) return 0;
-    if (params->rgba_dtype != GMPI_DTYPE_BF16) return 0;  // (the band kernel takes bf16 volumes only)
-    const int64_t bands = static_cast<int64_t>(p.N) * ((p.W + 255) / 256) * ((p.H + 7) / 8);
-    if (params->variant == GMPI_VARIANT_BAND || (params->variant == GMPI_VARIANT_AUTO && bands >= kAutoBandMin)) return band_workspace_bytes(p);
+    if (params->rgba_dtype == GMPI_DTYPE_F16) return 0;  // (the band kernel takes bf16 and fp32 volumes)
+    if (params->variant == GMPI_VARIANT_BAND) return band_workspace_bytes(p, params->rgba_dtype);
+    if (params->variant == GMPI_VARIANT_AUTO && auto_takes_band(p, params->rgba_dtype)) return band_workspace_bytes(p, params->rgba_dtype);
     return 0;
 }
 
@@ -474,6 +481,7 @@ int gmpi_query(int32_t what) {
         case 7: return 1;  // GMPI_VARIANT_DMA is built in
         case 8: return 1;  // GMPI_VARIANT_BAND is built in
         case 9: return static_cast<int>(kAutoBandMin);
+        case 10: return static_cast<int>(kAutoBandMinF32);
         default: return -1;
     }
 }

@@ -28,11 +28,7 @@ namespace gmpi {
 namespace band {
 
 constexpr int kNT = 1024;              // threads per workgroup (16 wavefronts)
-constexpr int NSB = 4;                 // sub-blocks per band
-constexpr int SBW = 64, SBH = 8;       // sub-block: 64 x 8 pixels = 4 waves x 2 pixels per thread
-constexpr int PPT = 2;                 // pixels per thread: rows j, j + 4 of the sub-block (j = wave % 4)
-constexpr int WPS = SBH / PPT;         // waves per sub-block
-constexpr int kSubLanes = 64 * WPS;    // loader lanes per sub-block
+constexpr int SBW = 64, SBH = 8;       // sub-block: 64 x 8 pixels
 constexpr float kBoxEps = 1.0f / 64;
 constexpr float kCoordLimit = 16384.0f;
 
@@ -43,21 +39,30 @@ template <int V> using ic = std::integral_constant<int, V>;
 template <int D0, int STEP>
 __device__ __forceinline__ void dma16x2(uint32_t voff, uint32_t soff1, const u32x4& rsrc, uint32_t lds_dst, uint64_t m0, uint64_t m1);
 
+// The band of a workgroup by storage type -- the same LDS budget (two staging buffers of 15 texel rows x 80 texels per sub-block = 76.8 KB, two
+// workgroups per CU) buys
+//   bf16: 4 sub-blocks = 256 x 8 pixels, 4 waves per sub-block, 2 pixels per thread (rows j, j + 4);
+//   fp32: 2 sub-blocks = 128 x 8 pixels, 8 waves per sub-block, 1 pixel per thread -- a texel row of a box is 576 bytes either way.
 template <typename TexT> struct Geo {
     static constexpr int kES = static_cast<int>(sizeof(TexT));
+    static constexpr int NSB = kES == 2 ? 4 : 2;            // sub-blocks per band
+    static constexpr int PPT = kES == 2 ? 2 : 1;            // pixels per thread: rows j + WPS q of the sub-block (j = wave % WPS)
+    static constexpr int WPS = SBH / PPT;                   // waves per sub-block
+    static constexpr int kSubLanes = 64 * WPS;              // loader lanes per sub-block
+    static_assert(NSB * WPS * 64 == kNT, "waves");
     static constexpr int kTPI = 16 / kES;                   // texels per 16-byte item
     static constexpr int kCols = kES == 2 ? 10 : 20;        // items per (row, channel) line: 80 texels
     static constexpr int kLineBytes = kCols * 16;
     static constexpr int kRowBytes = 4 * kLineBytes;
     static constexpr int kIPR = 4 * kCols;                  // items per texel row
-    static constexpr int kMaxRows = kES == 2 ? 15 : 7;      // rows per sub-block buffer
+    static constexpr int kMaxRows = 15;                     // rows per sub-block buffer
     static constexpr int kCapItems = kMaxRows * kIPR;
-    static constexpr int kSubBytes = kCapItems * 16;        // 9600 (bf16)
+    static constexpr int kSubBytes = kCapItems * 16;        // 9600 (bf16) / 19200 (fp32)
     static constexpr int kBufBytes = NSB * kSubBytes;
     // One DMA pass of a sub-block's lanes moves kRPP whole texel rows (lanes beyond kRPP * kIPR idle): a lane's item of pass r is its item
     // of pass 0 moved down by r * kRPP rows -- one per-lane offset register, the pass in the instruction's scalar offset.
-    static constexpr int kRPP = kSubLanes / kIPR;           // 6 (bf16) / 3 (fp32) rows per pass
-    static constexpr int kPassItems = kRPP * kIPR;          // 240 active lanes
+    static constexpr int kRPP = kSubLanes / kIPR;           // 6 rows per pass
+    static constexpr int kPassItems = kRPP * kIPR;          // 240 (bf16) / 480 (fp32) active lanes
     static constexpr int kNP = 3;                           // DMA passes per plane at most
     static_assert((kMaxRows + kRPP - 1) / kRPP <= kNP, "passes");
     static constexpr int kOffBytes = kNT * 4;               // per-lane loader offsets (kept in LDS: a VGPR through the plane loop is dearer)
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const
                                                          uint4* __restrict__ recs, uint4* __restrict__ pl, uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes;
+    constexpr int NSB = G::NSB;
     static_assert(kCols < 32 && kMaxRows < 16, "shape_pack");
     const int band_id = blockIdx.x;
     int n, brem;
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                                                          const uint4* __restrict__ recs, const uint4* __restrict__ pl, const uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kNP = G::kNP;
+    constexpr int NSB = G::NSB, PPT = G::PPT, WPS = G::WPS, kSubLanes = G::kSubLanes;
     constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
     constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
     constexpr bool BF = kES == 2;
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
             gp_c = Ln.w;  // (Ln is still the record of plane tt + 1)
             Ln = myrec[static_cast<int64_t>(tt + 2) * kRecStep];
             Fc = mypl[(tt + 1) * kPlU4], rhh_c = mypl[(tt + 1) * kPlU4 + 1].x;
-            static_assert(PPT == 2 && kNP <= 3, "pixel slots / check passes");
+            static_assert(PPT <= 2 && kNP <= 3, "pixel slots / check passes");
         };
         // (the per-pixel state must sit in registers through the plane loop: a reload there is a vector memory operation on the DMA's counter)
 #pragma unroll
@@ -627,24 +634,26 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
 #endif
 }
 
-static void band_grid(const KParams& p, int& bands_x, int& bands_y, int& n_bands) {
-    bands_x = (p.W + NSB * SBW - 1) / (NSB * SBW), bands_y = (p.H + SBH - 1) / SBH;
+static int nsb_of(int dtype) { return dtype == 1 ? Geo<bf16_t>::NSB : Geo<float>::NSB; }
+static void band_grid(const KParams& p, int nsb, int& bands_x, int& bands_y, int& n_bands) {
+    bands_x = (p.W + nsb * SBW - 1) / (nsb * SBW), bands_y = (p.H + SBH - 1) / SBH;
     n_bands = bands_x * bands_y * p.N;
 }
 // workspace: [n_bands] header words + [N] view gate words | (N * D + 2) plane records of 32 bytes | (n_bands * D + 2) * NSB box records of 16 bytes (each part 256-aligned)
 static uint64_t align256(uint64_t v) { return (v + 255) / 256 * 256; }
 static uint64_t ws_hdr_bytes(int n_bands, int n_views) { return align256((static_cast<uint64_t>(n_bands) + n_views) * 4); }
 static uint64_t ws_pl_bytes(const KParams& p) { return align256((static_cast<uint64_t>(p.N) * p.D + 2) * kPlU4 * 16); }
-static uint64_t ws_bytes(const KParams& p) {
+static uint64_t ws_bytes(const KParams& p, int nsb) {
     int bx, by, nb;
-    band_grid(p, bx, by, nb);
-    return ws_hdr_bytes(nb, p.N) + ws_pl_bytes(p) + (static_cast<uint64_t>(nb) * p.D + 2) * NSB * 16;
+    band_grid(p, nsb, bx, by, nb);
+    return ws_hdr_bytes(nb, p.N) + ws_pl_bytes(p) + (static_cast<uint64_t>(nb) * p.D + 2) * nsb * 16;
 }
 
 template <typename TexT>
 static hipError_t launch_t(const KParams& p, hipStream_t stream) {
+    constexpr int NSB = Geo<TexT>::NSB;
     int bands_x, bands_y, n_bands;
-    band_grid(p, bands_x, bands_y, n_bands);
+    band_grid(p, NSB, bands_x, bands_y, n_bands);
     const dim3 grid(xcd_grid_per_group(bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands)), block(kNT);
     const bool acf = p.flags & 1u;
     const float cx = acf ? static_cast<float>(p.Wt - 1) * 0.5f : static_cast<float>(p.Wt), cy = acf ? static_cast<float>(p.Ht - 1) * 0.5f : static_cast<float>(p.Ht);
@@ -670,23 +679,23 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
 
 }  // namespace band
 
-uint64_t band_workspace_bytes(const KParams& p) { return band::ws_bytes(p); }
+uint64_t band_workspace_bytes(const KParams& p, int dtype) { return band::ws_bytes(p, band::nsb_of(dtype)); }
+int band_pixels_wide(int dtype) { return band::nsb_of(dtype) * band::SBW; }
 
 // the view gate words of the workspace (KParams::gate of an AUTO launch)
-uint32_t* band_gate_words(const KParams& p) {
+uint32_t* band_gate_words(const KParams& p, int dtype) {
     int bx, by, nb;
-    band::band_grid(p, bx, by, nb);
+    band::band_grid(p, band::nsb_of(dtype), bx, by, nb);
     return static_cast<uint32_t*>(p.ws) + nb;
 }
 
 bool band_variant_supports(const KParams& p, int dtype) {
-    // bf16 volumes only.  fp16: a d16 load yields the half's bits, not an fp32 value (render_lds.hip converts while staging).  fp32: a plane's
-    // boxes are twice the bytes -- two staging buffers of 15 rows no longer leave room for two workgroups per CU, and with 7 rows hardly a
-    // band fits -- and the tile kernel already reaches 0.6-0.7 of the HBM rate there (profiles/README.md), so the geometry below stays untested.
-    if (dtype != 1) return false;
-    if (p.ws == nullptr || p.ws_bytes < band::ws_bytes(p) || reinterpret_cast<uintptr_t>(p.ws) % 256 != 0) return false;  // needs the caller's workspace
-    if (static_cast<int64_t>(p.N) * p.D * ((p.W + 255) / 256) * ((p.H + 7) / 8) > (int64_t(1) << 28)) return false;  // record indices stay in 32 bits
-    const int es = 2, tpi = 16 / es;
+    // bf16 and fp32 volumes.  fp16: a d16 load yields the half's bits, not an fp32 value (render_lds.hip converts while staging).
+    if (dtype != 0 && dtype != 1) return false;
+    const int nsb = band::nsb_of(dtype), bw = nsb * band::SBW;
+    if (p.ws == nullptr || p.ws_bytes < band::ws_bytes(p, nsb) || reinterpret_cast<uintptr_t>(p.ws) % 256 != 0) return false;  // needs the caller's workspace
+    if (static_cast<int64_t>(p.N) * p.D * ((p.W + bw - 1) / bw) * ((p.H + 7) / 8) > (int64_t(1) << 28)) return false;  // record indices stay in 32 bits
+    const int es = dtype == 0 ? 4 : 2, tpi = 16 / es;
     if (p.Wt % tpi != 0) return false;
     if (reinterpret_cast<uintptr_t>(p.rgba) % 16 != 0) return false;
     if (p.s_row % tpi != 0 || p.s_chan % tpi != 0 || p.s_plane % tpi != 0 || p.s_mpi % tpi != 0) return false;
@@ -703,8 +712,9 @@ hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t strea
 #else
     (void)tune;
 #endif
-    if (dtype != 1) return hipErrorInvalidValue;
-    return band::launch_t<bf16_t>(p, stream);
+    if (dtype == 1) return band::launch_t<bf16_t>(p, stream);
+    if (dtype == 0) return band::launch_t<float>(p, stream);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace gmpi

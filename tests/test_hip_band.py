@@ -1,7 +1,7 @@
-"""GPU parity tests of the round-3 kernels that only take bf16 volumes -- the band kernel (GMPI_VARIANT_BAND, render_band.hip), the LDS-DMA tile
-kernel (GMPI_VARIANT_DMA, render_dma.hip) -- and of GMPI_VARIANT_AUTO's two-kernel launch that shares the views between the band kernel and the
-tile kernel on the device.  Same bars as test_hip_parity.py: strict-order mode == oracle bit for bit, default mode within 1e-5.
-The volume is stored as bf16; the oracle renders its exact fp32 upcast (mpi_renderer.py:446)."""
+"""GPU parity tests of the round-3 kernels -- the band kernel (GMPI_VARIANT_BAND, render_band.hip: 256 x 8 pixel bands over bf16 volumes, 128 x 8
+over fp32 volumes), the LDS-DMA tile kernel (GMPI_VARIANT_DMA, render_dma.hip: bf16) -- and of GMPI_VARIANT_AUTO's two-kernel launch that shares
+the views between the band kernel and the tile kernel on the device.  Same bars as test_hip_parity.py: strict-order mode == oracle bit for bit,
+default mode within 1e-5.  A bf16 volume is rendered by the oracle as its exact fp32 upcast (mpi_renderer.py:446)."""
 import ctypes
 
 import numpy as np
@@ -34,6 +34,28 @@ def _check(stored, dhw, ray, eye, zd, variants=BF, **kw):
         assert np.abs(fast["depth"] - orc["depth"]).max() <= TOL, variant
         assert np.abs(fast["T"] - orc["T"]).max() <= TOL, variant
     return orc
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(seed=26, B=2, D=12, S=256),                        # fp32: two band columns of 128 pixels
+    dict(seed=27, B=2, D=7, S=200, T=204),                  # fp32: ragged image, texture != image (a multiple of 4 texels)
+    dict(seed=28, B=2, D=9, S=320, T=256, extreme=True),    # fp32: tilted cameras -> boxes that do not fit, rays that leave the texture
+])
+def test_band_parity_fp32(cfg):
+    rgba, dhw, ray, eye, zd = _random_case(**cfg)
+    _check(rgba, dhw, ray, eye, zd, variants=("band", "auto"))
+
+
+def test_auto_shares_views_fp32():
+    """The fp32 form of test_auto_shares_views_between_band_and_tile_kernels (AUTO's band path from gmpi_query(10) bands of 128 x 8 pixels)."""
+    lib = _lib().load_library()
+    S, B, D = 512, 4, 5
+    assert B * ((S + 127) // 128) * ((S + 7) // 8) >= lib.gmpi_query(10)
+    rgba, dhw, ray, eye, zd = _random_case(seed=33, B=B, D=D, S=S)
+    _, _, ray_x, eye_x, zd_x = _random_case(seed=34, B=B, D=D, S=S, extreme=True)
+    for n in (0, 2):
+        ray[n], eye[n], zd[n] = ray_x[n], eye_x[n], zd_x[n]
+    _check(rgba, dhw, ray, eye, zd, variants=("auto", "band"))
 
 
 @pytest.mark.parametrize("cfg", [
@@ -155,7 +177,7 @@ def test_workspace_contract():
         p.struct_size = ctypes.sizeof(L.GmpiRenderParams)
         p.flags = L.FLAG_ALIGN_CORNERS | L.FLAG_STRICT_ORDER
         p.variant = L.VARIANTS[variant]
-        p.rgba_dtype = {torch.float32: L.DTYPE_F32, torch.bfloat16: L.DTYPE_BF16}[vol.dtype]
+        p.rgba_dtype = {torch.float32: L.DTYPE_F32, torch.bfloat16: L.DTYPE_BF16, torch.float16: L.DTYPE_F16}[vol.dtype]
         p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W, p.views_per_mpi = 2, 2, 4, 256, 256, 256, 256, 1
         p.rgba = vol.data_ptr()
         for i, s in enumerate(vol.stride()):
@@ -168,7 +190,8 @@ def test_workspace_contract():
     need = lib.gmpi_render_workspace_bytes(ctypes.byref(p))
     assert need > 0
     assert lib.gmpi_render_workspace_bytes(ctypes.byref(params("auto", d[0]))) == 0   # 64 bands: below AUTO's band threshold
-    assert lib.gmpi_render_workspace_bytes(ctypes.byref(params("band", d[0].float()))) == 0  # fp32 volume: no kernel wants scratch
+    assert lib.gmpi_render_workspace_bytes(ctypes.byref(params("band", d[0].float()))) > need  # fp32: twice the bands (128 pixels wide)
+    assert lib.gmpi_render_workspace_bytes(ctypes.byref(params("band", d[0].to(torch.float16)))) == 0  # fp16 volume: no kernel wants scratch
     assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == E_VARIANT            # no workspace
     ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
     p.workspace, p.workspace_bytes = ws.data_ptr(), need - 1
@@ -180,9 +203,9 @@ def test_workspace_contract():
     torch.cuda.synchronize()
     orc = oracle.render(rgba.float(), dhw, ray, eye, zd)
     assert np.array_equal(color.cpu().numpy(), orc["color"]) and int(status[0]) == 0
-    pf = params("band", d[0].float())
-    pf.workspace, pf.workspace_bytes = ws.data_ptr(), need
-    assert lib.gmpi_mpi_render_launch(ctypes.byref(pf), None) == E_VARIANT           # fp32 volumes are not the band kernel's
+    ph = params("band", d[0].to(torch.float16))
+    ph.workspace, ph.workspace_bytes = ws.data_ptr(), need
+    assert lib.gmpi_mpi_render_launch(ctypes.byref(ph), None) == E_VARIANT           # fp16 volumes are not the band kernel's
 
 
 def test_frontal_hint_changes_no_result():

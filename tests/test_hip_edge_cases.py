@@ -125,6 +125,8 @@ def test_guard_band_no_read_outside_the_volume(dtype):
     for ac in (True, False):
         ref = None
         for variant in variants():
+            if variant == "band" and dtype == torch.float16:
+                continue  # (refused for fp16 volumes: GMPI_E_VARIANT)
             for strict in (True, False):
                 mpi = MPI(align_corners=ac, variant=variant, strict_order=strict, range_check="touched", on_out_of_plane="raise")
                 with torch.no_grad():

@@ -25,12 +25,14 @@ def _lib():
 
 
 def variants(bf16=False):
-    """Kernel variants built into the library; bf16=True adds the ones that only take bf16 volumes (LDS-DMA tile and band kernels)."""
+    """Kernel variants built into the library (the band kernel takes fp32 and bf16 volumes and is refused -> AUTO for fp16);
+    bf16=True adds the LDS-DMA tile kernel, which only takes bf16 volumes."""
     L = _lib()
     lib = L.load_library()
     v = ["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
+    v += (["band"] if lib.gmpi_query(8) > 0 else []) + ["auto"]
     if bf16:
-        v += (["dma"] if lib.gmpi_query(7) > 0 else []) + (["band"] if lib.gmpi_query(8) > 0 else []) + ["auto"]
+        v += ["dma"] if lib.gmpi_query(7) > 0 else []
     return v
 
 

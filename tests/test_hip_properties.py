@@ -23,7 +23,9 @@ DEV = "cuda:0"
 def variants():
     from ml_gmpi_amd import _lib as L
     lib = L.load_library()
-    return ["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
+    # (all shapes of this file store fp32 or bf16: the band kernel takes them; "auto" = band kernel + gated tile kernel at these sizes)
+    return (["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
+            + (["band"] if lib.gmpi_query(8) > 0 else []) + ["auto"])
 
 
 def setup(S, D, B, preset="FFHQ", dtype=torch.float32, seed=0, last_alpha_one=False, extreme=False):

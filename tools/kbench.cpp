@@ -79,7 +79,9 @@ int main(int argc, char** argv) {
     {  // workspace for the kernels that want one (GMPI_VARIANT_BAND)
         auto wsb = (uint64_t (*)(const GmpiRenderParams*))dlsym(h, "gmpi_render_workspace_bytes");
         p.flags = GMPI_FLAG_ALIGN_CORNERS;
+        p.variant = GMPI_VARIANT_BAND;  // (what the band kernel wants: AUTO asks for the same or for nothing)
         const uint64_t need = wsb ? wsb(&p) : 0;
+        p.variant = GMPI_VARIANT_AUTO;
         if (need) { CK(hipMalloc(&p.workspace, need)); p.workspace_bytes = need; printf("workspace %.1f MB\n", need / 1e6); }
     }
     std::vector<float> ref_rgb, ref_dep, rgb(npix * 3), dep(npix);
