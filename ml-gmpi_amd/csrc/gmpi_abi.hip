@@ -270,6 +270,10 @@ constexpr int64_t kAutoBandMinF32 = 1024;  // fp32: bands of 128 x 8 pixels (at 
 // does GMPI_VARIANT_AUTO consider the band kernel for this launch (given a workspace and the band kernel's alignment preconditions)?
 static bool auto_takes_band(const KParams& p, int dtype) {
     if (dtype != GMPI_DTYPE_BF16 && dtype != GMPI_DTYPE_F32) return false;
+    // Views that share one MPI (views_per_mpi > 1: the video paths) stay with the tile kernel: it interleaves them per tile so that the
+    // volume is read from HBM about once for the whole group (0.33x the algorithmic bytes on config 4) -- sharing the VIEWS out between two
+    // kernels would read it once per kernel (measured on config 4: 1.14 ms against 0.545).
+    if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) return false;
     const int bw = band_pixels_wide(dtype);
     return static_cast<int64_t>(p.N) * ((p.W + bw - 1) / bw) * ((p.H + 7) / 8) >= (dtype == GMPI_DTYPE_BF16 ? kAutoBandMin : kAutoBandMinF32);
 }

@@ -1,22 +1,23 @@
-// render_band.hip -- GMPI_VARIANT_BAND: 256 x 8 pixel bands, 4 pixels per thread, texel boxes moved HBM -> LDS by the LDS-DMA path.
+// render_band.hip -- GMPI_VARIANT_BAND: 256 x 8 (bf16 volumes) / 128 x 8 (fp32 volumes) pixel bands, texel boxes moved HBM -> LDS by the LDS-DMA path.
 //
 // Why (round 3).  Two measurements decide the shape (profiles/r03_band_loader.txt, r03_probe.txt):
 //  * the MEMORY side of a tile decomposition depends on how long the contiguous pieces are that a workgroup asks for in one plane
 //    step: with nothing but the loads running, 32 x 16 pixel tiles (80-byte pieces of a bf16 volume) take 0.92 ms for BASELINE
 //    config 3 however deep the prefetch and however the loads are issued (dword loads, 16-byte loads, LDS-DMA: the same), 128 x 8
-//    bands 0.78-0.80 ms, 256 x 8 bands (528-byte pieces, the rows of a box fill whole 128-byte lines) 0.56 ms = the rate of a
-//    streaming read -- at 2 or 3 workgroups of 512 threads per CU;
+//    bands 0.78-0.80 ms, 256 x 8 bands (528-byte pieces, the rows of a box fill whole 128-byte lines) 0.58 ms = the rate of a
+//    streaming read -- at 2 workgroups of 1024 threads per CU;
 //  * the COMPUTE side is bound by instruction issue and by what a plane step costs besides the pixels: the coordinate chain,
 //    16 taps, bilinear and blend are 55 VALU instructions per pixel and plane (51 of them in the 1.0-1.1 ns class), but a 32 x 16
 //    tile kernel pays 19 VALU + 41 SALU + a barrier per 64 pixels on top (loader, range check, table reads).
-// So: a workgroup of 512 threads owns a 256 x 8 pixel band = 4 sub-blocks of 64 x 8 pixels; two waves per sub-block, every thread
-// 4 pixels (column x, rows j, j+2, j+4, j+6): the per-plane overhead is paid once per 256 pixels of a wave, and the 4 pixels are
-// software-pipelined by hand (taps of pixel p in flight while the coordinate chain of pixel p+1 issues), which is what hides the
-// LDS round trip at 4 waves per SIMD.  Each sub-block has its own texel box (a tilted camera shears the band: one box would be
-// up to 54 rows tall, the sub-blocks' boxes 6-14), staged exactly as in render_dma.hip: raw texels, planar [row][channel][x],
-// one DMA item = 16 bytes of a channel row, lane-linear LDS image, exec-masked DMA instructions, zeros padding by the buffer
-// range check, one s_barrier per plane, taps by ds_read_u16_d16_hi (bf16: the loaded half IS the fp32 value) / ds_read2_b32.
-// A band whose boxes do not fit is rendered in 2 or 4 row groups (64 x 4 / 64 x 2 pixel sub-blocks), then by the direct gather.
+// So: a workgroup of 1024 threads owns a band of sub-blocks of 64 x 8 pixels (struct Geo: bf16 4 sub-blocks x 4 waves x 2 pixels per
+// thread, fp32 2 sub-blocks x 8 waves x 1 pixel per thread -- the texel rows of a band's boxes are 576 bytes either way).  Each
+// sub-block has its own texel box per plane (a tilted camera shears a 256-pixel band over up to 54 texel rows, a sub-block over
+// 6-14), staged as raw texels, planar [row][channel][x], one DMA item = 16 bytes of a channel row, lane-linear LDS image,
+// exec-masked DMA instructions, zeros padding by the buffer range check, two staging buffers, ONE s_barrier per plane, taps by
+// ds_read_u16_d16_hi (bf16: the loaded half IS the fp32 value) / ds_read2_b32.  What is uniform per (band, plane, sub-block) comes
+// from a table a small kernel writes into the caller's workspace in front of the render kernel (scalar loads, no LDS table).
+// A band with a box that does not fit its buffers (strongly tilted camera) is rendered by the direct gather; GMPI_VARIANT_AUTO
+// hands the whole VIEW to the tile kernel instead (KParams::gate, gmpi_abi.hip).
 // Arithmetic: gmpi_device.hpp (bit-identical to the oracle in strict-order mode).
 #include "gmpi_device.hpp"
 
