@@ -244,6 +244,13 @@ int gmpi_alpha_depth_backward_launch(const void *alpha, int32_t alpha_dtype, int
  */
 int gmpi_selftest_division_launch(uint64_t pairs, uint32_t seed, uint64_t *mismatches, void *stream);
 
+/*
+ * Diagnostic: one read-only pass over `bytes` of device memory with the fastest read pattern measured on gfx950 (non-temporal dword loads,
+ * profiles/r03_calibration.txt).  bench.py times it over the render's own volume and quotes the rate as `roofline.stream_read_gbs`: what a
+ * kernel that did nothing but read the volume would reach on this box.  `sink` (4 bytes, may be NULL) only keeps the loads alive.
+ */
+int gmpi_stream_probe_launch(const void *buf, uint64_t bytes, uint32_t *sink, void *stream);
+
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
  * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height, 6 whether
  * GMPI_VARIANT_WAVE is built in, 7 GMPI_VARIANT_DMA, 8 GMPI_VARIANT_BAND, 9 the number of 256 x 8 pixel bands from which

@@ -35,6 +35,7 @@ EXPORTS = (
     "gmpi_light_apply_backward_launch",
     "gmpi_alpha_depth_backward_launch",
     "gmpi_selftest_division_launch",
+    "gmpi_stream_probe_launch",
     "gmpi_query",
     "gmpi_version_string",
 )
@@ -153,6 +154,8 @@ def load_library():
     lib.gmpi_alpha_depth_backward_launch.argtypes = [vp, ctypes.c_int32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, vp,
                                                      vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
+    lib.gmpi_stream_probe_launch.restype = ctypes.c_int
+    lib.gmpi_stream_probe_launch.argtypes = [vp, ctypes.c_uint64, vp, vp]
     lib.gmpi_selftest_division_launch.restype = ctypes.c_int
     lib.gmpi_selftest_division_launch.argtypes = [ctypes.c_uint64, ctypes.c_uint32, vp, vp]
     lib.gmpi_query.restype = ctypes.c_int

@@ -102,6 +102,19 @@ __global__ __launch_bounds__(256) void range_check_vec_kernel(const uint4* __res
     report_status(status, bad ? 2u : 0u);
 }
 
+// ---- diagnostic: a pure streaming read (the ceiling bench.py quotes next to the render kernel's rate) -------------------------------
+// Non-temporal 4-byte loads, 32 per lane in flight, 2 workgroups per CU: the fastest read pattern of profiles/r03_calibration.txt
+// (7.0-7.4 TB/s on MI355X; cached loads and 16-byte loads stream at 6.3-7.1).
+__global__ __launch_bounds__(256) void stream_probe_kernel(const uint32_t* __restrict__ v, int64_t nwords, uint32_t* sink) {
+    uint32_t acc = 0;
+    const int64_t trip = static_cast<int64_t>(256) * 32, stride = static_cast<int64_t>(gridDim.x) * trip;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * trip + threadIdx.x; i + 31 * 256 < nwords; i += stride) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) acc |= __builtin_nontemporal_load(v + i + u * 256);
+    }
+    if (acc == 0x9e3779b9u && sink != nullptr) sink[0] = acc;  // (keeps the loads alive; a volume of [0, 1] values never has this OR)
+}
+
 // ---- driver epilogue: float frames -> uint8 (render_video.py:118-126) -------------------------------
 __global__ __launch_bounds__(256) void frames_to_uint8_kernel(const float* __restrict__ rgb, const float* __restrict__ dep,
                                                               int64_t HW, int64_t total, float dnear, float span,
@@ -472,6 +485,15 @@ int gmpi_selftest_division_launch(uint64_t pairs, uint32_t seed, uint64_t* misma
     const unsigned blocks = static_cast<unsigned>(want < 256u * 64u ? want : 256u * 64u);
     hipLaunchKernelGGL(selftest_division_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), pairs, seed,
                        reinterpret_cast<unsigned long long*>(mismatches));
+    return hip_rc(hipGetLastError());
+}
+
+int gmpi_stream_probe_launch(const void* buf, uint64_t bytes, uint32_t* sink, void* stream) {
+    if (buf == nullptr) return GMPI_E_NULL;
+    if (reinterpret_cast<uintptr_t>(buf) % 4 != 0) return GMPI_E_STRIDE;
+    if (bytes < 4) return GMPI_OK;
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(256 * 2), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const uint32_t*>(buf),
+                       static_cast<int64_t>(bytes / 4), sink);
     return hip_rc(hipGetLastError());
 }
 

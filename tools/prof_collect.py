@@ -76,7 +76,7 @@ for wl in ("cfg3", "cfg2", "cfg3_f32", "cfg4", "cfg5"):
     if not os.path.isdir(d):
         continue
     print(f"== {wl}")
-    ent = {"variant": "auto", "source": f"profiles/{os.path.basename(out)}_summary.txt"}
+    ent = {"variant": "auto", "source": f"profiles/{os.path.basename(out).replace('prof_', '')}_prof_summary.txt"}
     for p in sorted(glob.glob(os.path.join(d, "pmc_*"))):
         means, kname = pmc_means(p)
         if kname:
