@@ -105,6 +105,30 @@ __global__ void valu_kernel(float* out, int iters) {
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
+// packed fp32 (VOP3P on 64-bit register pairs): two results per lane and instruction
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__global__ void valu_pk_kernel(float* out, int iters) {
+    f32x2 a0 = {threadIdx.x * 0.37f, 1.0f}, a1 = a0 + 1.3f, a2 = a0 + 2.1f, a3 = a0 + 3.7f, a4 = a0 + 4.2f, a5 = a0 + 5.9f, a6 = a0 + 6.4f, a7 = a0 + 7.8f;
+    const f32x2 c = {1.0001f, 0.9999f}, d = {0.5f, 0.25f};
+    for (int i = 0; i < iters; ++i) {
+#define ASM8P(body) REP16(asm volatile(body : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(d));)
+        if (MODE == 0) { ASM8P("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %8, %9\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %8, %9\n v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %8, %9\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %8, %9\n") }
+        if (MODE == 1) { ASM8P("v_pk_mul_f32 %0, %1, %8\n v_pk_mul_f32 %1, %2, %8\n v_pk_mul_f32 %2, %3, %8\n v_pk_mul_f32 %3, %4, %8\n v_pk_mul_f32 %4, %5, %8\n v_pk_mul_f32 %5, %6, %8\n v_pk_mul_f32 %6, %7, %8\n v_pk_mul_f32 %7, %0, %8\n") }
+        if (MODE == 2) { ASM8P("v_pk_add_f32 %0, %1, %8\n v_pk_add_f32 %1, %2, %8\n v_pk_add_f32 %2, %3, %8\n v_pk_add_f32 %3, %4, %8\n v_pk_add_f32 %4, %5, %8\n v_pk_add_f32 %5, %6, %8\n v_pk_add_f32 %6, %7, %8\n v_pk_add_f32 %7, %0, %8\n") }
+    }
+    const f32x2 r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r.x + r.y;
+}
+template <int MODE> static void run_valu_pk(const char* name, int wps) {
+    float* out; const int block = 64 * 4 * wps; CK(hipMalloc(&out, 256 * block * 4));
+    const int iters = 1500; hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    valu_pk_kernel<MODE><<<256, block>>>(out, 10);
+    hipEventRecord(e0); valu_pk_kernel<MODE><<<256, block>>>(out, iters); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("  %-22s waves/SIMD=%d  %.3f ns per wave-instr per SIMD (two fp32 results per lane)\n", name, wps, ms * 1e6 / ((double)iters * 128 * wps));
+    hipFree(out);
+}
 template <int MODE> static void run_valu(const char* name, int wps) {
     float* out; const int block = 64 * 4 * wps; CK(hipMalloc(&out, 256 * block * 4));
     const int iters = 1500; hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -252,6 +276,7 @@ int main(int argc, char** argv) {
     ramp();
     if (!strcmp(what, "valu")) {
         if (argc > 2) {  // the candidates of the band kernel's range-check fold
+            run_valu_pk<0>("v_pk_fma_f32", 4); run_valu_pk<1>("v_pk_mul_f32", 4); run_valu_pk<2>("v_pk_add_f32", 4);
             run_valu<16>("v_max3_u16 op_sel", 4); run_valu<17>("v_pk_max_u16", 4); run_valu<18>("v_max3_u32", 4); run_valu<19>("v_max_u32", 4); run_valu<20>("v_or_b32", 4); run_valu<0>("v_fma_f32", 4);
             return 0;
         }
