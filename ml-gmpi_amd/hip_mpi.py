@@ -37,6 +37,20 @@ def _workspace(dev: torch.device, stream: int, need: int) -> torch.Tensor:
     return ws
 
 
+# Status words of calls that read them back themselves (status=None, defer_status=False): one tensor per device and stream, zero between
+# calls -- a call that finds a bit set clears the words before it raises -- instead of a fresh `torch.zeros` (an allocation and a fill
+# kernel in front of every render).
+_STATUS = {}
+
+
+def _own_status(dev: torch.device, stream: int) -> torch.Tensor:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+    st = _STATUS.get(key)
+    if st is None:
+        st = _STATUS[key] = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+    return st
+
+
 def _f32_on(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
     """t as contiguous float32 on dev; the tensor itself when it already is (a no-op `.to().contiguous()` costs ~10 us per call)."""
     if t.dtype is torch.float32 and t.device == dev and t.is_contiguous():
@@ -196,7 +210,10 @@ class MPI(nn.Module):
             if T is None:
                 T = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
         if status is None:
-            status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+            if on_device and not defer_status and not _in_autograd_fn:
+                status = _own_status(dev, torch.cuda.current_stream(dev).cuda_stream)
+            else:
+                status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
 
         flags = 0
         if self._align_corners:
@@ -252,6 +269,8 @@ class MPI(nn.Module):
         word = int(status[0].item())  # the only host sync of a render call
         if word == 0:
             return
+        if any(status is st for st in _STATUS.values()):
+            status.zero_()  # (the shared words of this device and stream: clean for the next call)
         if word & _lib.STATUS_BAD_VIEW_INDEX:
             raise IndexError("view_to_mpi holds an index outside [0, #mpi)")
         if word & _lib.STATUS_RGBA_RANGE:

@@ -89,6 +89,7 @@ class MPIRenderer:
         self.ray_backend = ray_backend
         self._batched_cam = None
         self._dhw_dev = None
+        self._dhw_rep = None
         self._spec = None            # look-ahead pose queue (see _draw_poses)
         self._ray_bufs = {}          # render()'s own ray buffers (see _generate_rays_hip)
         self._frontal = False        # GMPI_FLAG_HINT_FRONTAL of the poses last drawn
@@ -300,6 +301,15 @@ class MPIRenderer:
         if n_calls > 0:
             self._look_ahead(self._pose_key(batch_size, hm, hs, vm, vs, random_pose), int(n_calls), batch_size, hm, hs, vm, vs)
 
+    def _dhw_for(self, n_mpis: int) -> torch.Tensor:
+        """[n_mpis, D, 3] plane geometry on the device, contiguous (the C ABI's layout), cached per batch size: an `expand`ed view would be
+        materialised by a copy kernel in front of every launch."""
+        base = self._dhw_on_device()
+        hit = self._dhw_rep
+        if hit is None or hit[0] is not base or hit[1].shape[0] != n_mpis:
+            hit = self._dhw_rep = (base, base.expand(n_mpis, -1, -1).contiguous())
+        return hit[1]
+
     def _generate_rays_hip(self, c2w: torch.Tensor, reuse: bool = False):
         """(ray_dir [B,3,H,W], eye_pos [B,3], z_dir [B,3]) for c2w [B,4,4] on the device -- one launch
         (`gmpi_generate_rays_launch`), same bits as the reference's CPU `Camera._generate_rays_torch`.
@@ -385,7 +395,7 @@ class MPIRenderer:
             self._batched_cam = None
         assert ray_t.shape[0] == batch_size, f"{ray_t.shape[0]}, {batch_size}"
 
-        dhw = self._dhw_on_device().expand(n_mpis, -1, -1)
+        dhw = self._dhw_for(n_mpis)
         res = self.mpi.render_views(
             batch_mpi_rgbas, dhw, ray_t, eye_t, zd_t, views_per_mpi=views_per_mpi,
             check_last_plane=assert_not_out_of_last_plane, out_pm1=True, want_transmittance=want_T,
