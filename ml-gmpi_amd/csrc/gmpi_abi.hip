@@ -288,7 +288,11 @@ static bool auto_takes_band(const KParams& p, int dtype) {
     // kernels would read it once per kernel (measured on config 4: 1.14 ms against 0.545).
     if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) return false;
     const int bw = band_pixels_wide(dtype);
-    return static_cast<int64_t>(p.N) * ((p.W + bw - 1) / bw) * ((p.H + 7) / 8) >= (dtype == GMPI_DTYPE_BF16 ? kAutoBandMin : kAutoBandMinF32);
+    const int64_t cols = (p.W + bw - 1) / bw, rows = (p.H + 7) / 8;
+    // (an image that fills less than 3/4 of its bands -- narrower than a band, a ragged last column -- wastes the idle lanes' issue slots:
+    //  the tile kernel's 32 x 16 tiles fit such images better)
+    if (static_cast<int64_t>(p.W) * 4 < cols * bw * 3 || static_cast<int64_t>(p.H) * 4 < rows * 8 * 3) return false;
+    return static_cast<int64_t>(p.N) * cols * rows >= (dtype == GMPI_DTYPE_BF16 ? kAutoBandMin : kAutoBandMinF32);
 }
 
 static int hip_rc(hipError_t e) { return e == hipSuccess ? GMPI_OK : GMPI_E_LAUNCH - static_cast<int>(e); }

@@ -701,7 +701,7 @@ bool band_variant_supports(const KParams& p, int dtype) {
     if (reinterpret_cast<uintptr_t>(p.rgba) % 16 != 0) return false;
     if (p.s_row % tpi != 0 || p.s_chan % tpi != 0 || p.s_plane % tpi != 0 || p.s_mpi % tpi != 0) return false;
     if (p.Ht > 8192 || p.Wt > 8192) return false;  // tap addresses are formed in fp32
-    const int64_t span = 3 * p.s_chan + 16 * p.s_row + 128;  // the in-plane item offset is kept in 32 bits
+    const int64_t span = 3 * p.s_chan + 18 * p.s_row + 128;  // the in-plane item offset (row < 6, + 2 passes of 6 rows, 3 channels) is kept in 32 bits
     if (span >= (int64_t(1) << 31) / es) return false;
     return true;
 }
