@@ -311,12 +311,12 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         return dot;
     };
 
-    // ---- this thread's loader items: item 128 r + (tid % 128) of its sub-block's box -> (texel row, channel, item column) ----
+    // ---- this thread's loader items: item kPassItems r + (tid % kSubLanes) of its sub-block's box -> (texel row, channel, item column) ----
     auto loader_pos = [&](int& l_col, int& l_line, int& l_row, bool& l_on) {  // pass 0: line = 4 row + channel
         const int t = fresh_tid() & (kSubLanes - 1);
         l_line = t / kCols, l_col = t - l_line * kCols, l_row = l_line >> 2, l_on = t < kPassItems;
     };
-    {  // byte offset of this lane's pass-0 item from the box origin: parked in LDS, read back with the per-plane burst
+    {  // byte offset of this lane's pass-0 item from the box origin: parked in LDS, read back behind every plane's barrier
         int l_col, l_line, l_row;
         bool l_on;
         loader_pos(l_col, l_line, l_row, l_on);
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
 #pragma unroll
         for (int q = 0; q < PPT; ++q) dots[q] = STRICT ? ray_dot(q) : 0.0f;  // (default mode applies the dot product once, at the end)
         // ---- per wave: exec masks / pass count of the box of the plane last issued (recomputed when the box shape changes: a handful of
-        //      times per band).  The range check of plane t runs BEFORE plane t + 1 is issued, so it sees plane t's masks. ----
+        //      times per band).  (`three` of plane t is latched before plane t + 1 is issued: the range check of plane t reads it.) ----
         uint64_t m_cur[kNP];
         int dims_cur = 0;
         bool three = false;  // the box of the plane last issued needs the third pass
@@ -495,9 +495,10 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         };
 
 
-        // One plane step.  The records come through scalar loads issued a step ahead (part L of plane t + 2 for the DMA of the next step,
-        // parts F, G of plane t + 1 for its pixels); this lane's items of the current plane (range check) and its loader offset come in one
-        // LDS burst behind the barrier.
+        // One plane step: barrier | loader offset (LDS) and DMA of plane t + 1 | this lane's landed items of plane t folded into the range
+        // check | the pixels | scalar loads of the next step's records (box record of plane t + 2, plane constants of plane t + 1).
+        // (Measured without effect and not kept, profiles/r03_band_variants.txt: the loader offset fetched before the barrier; s_setprio 3
+        //  around the DMA issue.)
         uint4 Ln, Fc;      // wave-uniform: scalar registers
         uint32_t rhh_c, gp_c;
         auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
