@@ -516,6 +516,6 @@ int gmpi_query(int32_t what) {
     }
 }
 
-const char* gmpi_version_string(void) { return "ml-gmpi_amd 0.1 (gfx950, ABI 1)"; }
+const char* gmpi_version_string(void) { return "ml-gmpi_amd 0.3 (gfx950, ABI 2)"; }
 
 }  // extern "C"
