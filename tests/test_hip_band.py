@@ -81,6 +81,11 @@ def test_auto_shares_views_between_band_and_tile_kernels():
     for n in (1, 3):
         ray[n], eye[n], zd[n] = ray_x[n], eye_x[n], zd_x[n]
     orc = _check(rgba, dhw, ray, eye, zd, variants=("auto", "band"))
+    # the same launch with an explicit view -> MPI table (a permutation: view n samples MPI B-1-n) takes AUTO's band path as well
+    perm = list(range(B - 1, -1, -1))
+    orc_p = oracle.render(rgba.float(), dhw, ray, eye, zd, view_to_mpi=np.array(perm, dtype=np.int32), threads=True)
+    out_p = hip_render(rgba, dhw, ray, eye, zd, variant="auto", strict=True, view_to_mpi=perm)
+    assert np.array_equal(out_p["color"], orc_p["color"]) and np.array_equal(out_p["depth"], orc_p["depth"])
     # dirty workspace: whatever the scratch held, every view is rendered exactly once (the gate words are stamped per launch)
     from ml_gmpi_amd import hip_mpi
     for ws in hip_mpi._WORKSPACES.values():
