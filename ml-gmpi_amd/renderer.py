@@ -94,6 +94,7 @@ class MPIRenderer:
         self._ray_bufs = {}          # render()'s own ray buffers (see _generate_rays_hip)
         self._frontal = False        # GMPI_FLAG_HINT_FRONTAL of the poses last drawn
         self._last_pose_key = None
+        self._spec_depth, self._spec_used_up, self._spec_penalty = 1, None, 0
         self.compute_mpi_spatial_volume()
         self.use_xyz_ztype = use_xyz_ztype
         self.use_normalized_xyz = use_normalized_xyz
@@ -233,7 +234,8 @@ class MPIRenderer:
     # if the default generator is still exactly in the state the look-ahead assumed (then it is moved to the state the call would have
     # left).  Anything else the program draws in between, a manual_seed, other arguments: the states differ, the queue is dropped and the
     # call draws for itself.  The look-ahead is therefore invisible: same poses, same RNG stream as the reference, call by call.
-    _SPEC_CALLS = 8
+    _SPEC_CALLS = 8       # depth of the first look-ahead of a repeating request; doubled at every refill that was used up, up to
+    _SPEC_CALLS_MAX = 32  # (a batch costs ~0.4 ms whatever its depth + ~10 us per call drawn)
 
     def _pose_key(self, batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std, random_pose):
         return (int(batch_size), float(horizontal_mean), float(horizontal_std), float(vertical_mean), float(vertical_std),
@@ -258,9 +260,13 @@ class MPIRenderer:
             return None
         j = sp["idx"]
         if not torch.equal(torch.get_rng_state(), sp["states"][j]):
+            # the program drew something else in between (a latent per iteration, say): what was drawn ahead is useless, and it will be again --
+            # the next calls of this request draw for themselves before a look-ahead is tried anew
             self._spec = None
+            self._spec_penalty = 16
             return None
         sp["idx"] = j + 1
+        self._spec_used_up = key if j + 1 == sp["n"] else None
         torch.set_rng_state(sp["states"][j + 1])                                    # as if this call had drawn
         self._frontal = sp["frontal"][j]
         return sp["yaws"][j], sp["pitches"][j], sp["c2w"][j], sp["angles"][j]
@@ -272,8 +278,18 @@ class MPIRenderer:
             key = self._pose_key(batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std, random_pose)
             hit = self._take_look_ahead(key)
             if hit is None:
-                # a request seen for the first time draws for itself only; one that repeats draws _SPEC_CALLS calls ahead
-                ahead = self._SPEC_CALLS if key == self._last_pose_key else 1
+                # a request seen for the first time draws for itself only; one that repeats draws _SPEC_CALLS calls ahead, and deeper
+                # every time a queue of it was used up to the last pose (a long loop: the batch cost is amortised further)
+                if key != self._last_pose_key:
+                    ahead = 1
+                elif self._spec_penalty > 0:
+                    self._spec_penalty -= 1
+                    ahead = 1
+                elif self._spec_used_up == key:
+                    ahead = min(2 * self._spec_depth, self._SPEC_CALLS_MAX)
+                else:
+                    ahead = self._SPEC_CALLS
+                self._spec_depth = ahead
                 self._look_ahead(key, ahead, batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std)
                 hit = self._take_look_ahead(key)
             self._last_pose_key = key
