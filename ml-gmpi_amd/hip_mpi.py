@@ -51,6 +51,14 @@ def _own_status(dev: torch.device, stream: int) -> torch.Tensor:
     return st
 
 
+def _on_device(dev: Optional[torch.device]):
+    """Context in which `dev` is the current ROCm device; nothing to do (and nothing to pay: two runtime calls per context otherwise) when
+    it already is."""
+    if dev is None or dev.index is None or torch.cuda.current_device() == dev.index:
+        return contextlib.nullcontext()
+    return torch.cuda.device(dev)
+
+
 def _f32_on(t: torch.Tensor, dev: torch.device) -> torch.Tensor:
     """t as contiguous float32 on dev; the tensor itself when it already is (a no-op `.to().contiguous()` costs ~10 us per call)."""
     if t.dtype is torch.float32 and t.device == dev and t.is_contiguous():
@@ -250,7 +258,7 @@ class MPI(nn.Module):
             if need:
                 ws = _workspace(dev, stream, need)
                 p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
-        with (torch.cuda.device(dev) if on_device else contextlib.nullcontext()):
+        with _on_device(dev if on_device else None):
             if self.range_check == "full":
                 vol = rgba if rgba.is_contiguous() else rgba.contiguous()
                 _lib.check(lib.gmpi_rgba_range_check_launch(vol.data_ptr(), p.rgba_dtype, vol.numel(),

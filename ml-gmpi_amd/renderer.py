@@ -286,7 +286,7 @@ class MPIRenderer:
                     self._spec_penalty -= 1
                     ahead = 1
                 elif self._spec_used_up == key:
-                    ahead = min(2 * self._spec_depth, self._SPEC_CALLS_MAX)
+                    ahead = min(max(2 * self._spec_depth, self._SPEC_CALLS), self._SPEC_CALLS_MAX)
                 else:
                     ahead = self._SPEC_CALLS
                 self._spec_depth = ahead
@@ -350,7 +350,8 @@ class MPIRenderer:
                     self._ray_bufs.clear()
                 self._ray_bufs[(B, H, W, stream)] = bufs
         ray, eye, zd = bufs
-        with torch.cuda.device(c2w.device):
+        from .hip_mpi import _on_device
+        with _on_device(c2w.device):
             _lib.check(lib.gmpi_generate_rays_launch(c2w.data_ptr(), dirs.data_ptr(), B, H, W, ray.data_ptr(), eye.data_ptr(),
                                                      zd.data_ptr(), stream), "gmpi_generate_rays_launch")
         return ray, eye, zd
