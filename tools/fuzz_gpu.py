@@ -24,6 +24,11 @@ for i in range(n_cases):
     H, W = (int(rng.integers(200, 700)), int(rng.integers(200, 700))) if big else (int(rng.integers(4, 200)), int(rng.integers(4, 200)))
     Ht, Wt = 8 * int(rng.integers(1, 80 if big else 30)), 8 * int(rng.integers(1, 80 if big else 30))
     D = int(rng.integers(1, 40 if big else 130))
+    if os.environ.get("FUZZ_LARGE"):  # launches large enough for AUTO's band path (and its view sharing): few planes keep the oracle quick
+        big = True
+        H, W = int(rng.integers(256, 1100)), int(rng.integers(256, 1100))
+        Ht, Wt = 8 * int(rng.integers(16, 140)), 8 * int(rng.integers(16, 140))
+        D = int(rng.integers(1, 12))
     B = int(rng.integers(1, 4)) if not (big and rng.random() < 0.3) else int(rng.integers(4, 9))   # (many views: AUTO's band + gated tile launch)
     preset = ["FFHQ", "AFHQCat", "MetFaces"][int(rng.integers(0, 3))]
     ac = bool(rng.integers(0, 2))
