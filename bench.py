@@ -7,7 +7,9 @@
 
 Metric (BASELINE.json): Mpix*planes/s = views*H*W*D / t / 1e6 (whole job, all GPUs), plus views/s and
 the fraction of the HBM roofline.  A "step" = ONE pass of the hot path over one batch of views
-(one fused kernel launch: warp + composite + depth + asserts), inputs resident in HBM.  Before the W warm-up steps the
+(one `gmpi_mpi_render_launch`: warp + composite + depth + asserts fused in one render kernel -- for large bf16 / fp32 launches the band
+kernel behind its small geometry-table kernel, plus the tile kernel's gated launch for views the band kernel cannot stage), inputs
+resident in HBM.  Before the W warm-up steps the
 same launch is repeated for --prewarm-ms (default 250 ms, untimed) so that a GPU coming from idle has reached its busy clocks.
 
 Default workload = BASELINE.json configs[2] ("FFHQ1024-shaped: 1024x1024, 96 planes, batch 4 views,
@@ -16,8 +18,8 @@ bf16", the configuration the north-star target is quoted on); each rank renders 
 fixed -- no data-path collective -> "weak" scaling).  The final frame all_gather
 (RCCL) is timed separately (`gather_ms`), outside the K timed steps.
 
-roofline.achieved = ALGORITHMIC bytes per launch / average kernel duration (HIP events around every
-launch on the launch stream).  Algorithmic bytes:
+roofline.achieved = ALGORITHMIC bytes per launch / the larger of (average duration of a step's kernels: HIP events around every
+launch call on the launch stream; wall time per step).  Algorithmic bytes:
     N*D*4*Ht*Wt*s_in  +  N*H*W*12 (ray_dir)  +  N*H*W*4*(3+1[+1]) (outputs)
 cpu_baseline = the CPU oracle (oracle/mpi_oracle.c, OpenMP build, kind "port") timed on this box's
 host cores on a bounded sample of the same workload -- a reported baseline, not the target.
