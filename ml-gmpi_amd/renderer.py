@@ -238,8 +238,10 @@ class MPIRenderer:
     _SPEC_CALLS_MAX = 32  # (a batch costs ~0.4 ms whatever its depth + ~10 us per call drawn)
 
     def _pose_key(self, batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std, random_pose):
+        # (sphere_r=None: gen_sphere_path takes the norm of the sphere centre, cam_utils.py:762-763)
+        sphere_r = float(np.linalg.norm(np.asarray(self.sphere_center, dtype=np.float64))) if self.sphere_r is None else float(self.sphere_r)
         return (int(batch_size), float(horizontal_mean), float(horizontal_std), float(vertical_mean), float(vertical_std),
-                bool(random_pose), self.cam_sample_method, float(self.cam_pose_n_truncated_stds), float(self.sphere_r),
+                bool(random_pose), self.cam_sample_method, float(self.cam_pose_n_truncated_stds), sphere_r,
                 tuple(float(v) for v in np.asarray(self.sphere_center, dtype=np.float64).reshape(-1)), str(self.device))
 
     def _look_ahead(self, key, n_calls, batch_size, hm, hs, vm, vs):
@@ -309,7 +311,8 @@ class MPIRenderer:
         """Draws the poses of the next `n_calls` calls of `render()` / `sample_cam_poses()` with these arguments NOW (the look-ahead the
         renderer starts by itself once a request repeats, with a chosen depth).  The default generator is NOT advanced: each call moves it
         when it takes its pose, and a call that finds it in another state than the look-ahead assumed draws for itself."""
-        assert random_pose, "a deterministic sweep has nothing to draw"
+        if not random_pose:
+            return  # a deterministic sweep has nothing to draw
         hm = self.horizontal_mean if horizontal_mean is None else horizontal_mean
         hs = self.horizontal_std if horizontal_std is None else horizontal_std
         vm = self.vertical_mean if vertical_mean is None else vertical_mean
@@ -393,7 +396,10 @@ class MPIRenderer:
             yaws, pitches, c2w, cam_angles = self._draw_poses(batch_size, horizontal_mean, horizontal_std, vertical_mean, vertical_std,
                                                               random_pose, given_yaws, given_pitches)
             frontal = self._frontal   # (known on the host: the poses were drawn here)
-            ray_t, eye_t, zd_t = self._generate_rays_hip(c2w, reuse=True)
+            # (the renderer's own ray buffers only when no autograd graph will hold them: `_RenderFunction` saves the camera tensors for its
+            #  backward, and the next render() of this shape would overwrite them through a raw pointer -- no version counter sees that)
+            recording = torch.is_grad_enabled() and batch_mpi_rgbas.requires_grad
+            ray_t, eye_t, zd_t = self._generate_rays_hip(c2w, reuse=not recording)
         else:
             if given_cam_infos is None:
                 yaws, pitches, c2w, rays, eyes, zdirs = self.sample_cam_poses(
