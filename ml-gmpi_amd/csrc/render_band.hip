@@ -18,6 +18,12 @@
 // from a table a small kernel writes into the caller's workspace in front of the render kernel (scalar loads, no LDS table).
 // A band with a box that does not fit its buffers (strongly tilted camera) is rendered by the direct gather; GMPI_VARIANT_AUTO
 // hands the whole VIEW to the tile kernel instead (KParams::gate, gmpi_abi.hip).
+// Round 4 (profiles/r04_band_variants.txt): the plane step of the bf16 default-mode instances is software-pipelined -- a batch of 8 taps is
+// issued one batch ahead of the wait that lands it, the range check's read-back leads the pipeline -- and the loader offset lives in a
+// vector register.  What the measurements of that round say about the rest: a wave's own DMA is NOT what it waits for at the barrier (393 of
+// 4600 cycles per plane with or without memory traffic); the wait is the skew between the 16 waves; the scalar loads of the next step's
+// records belong BEHIND the last pixel (the waves that arrive first warm the scalar cache for the last one: issued at the top of the step
+// they cost 5 %), and the records of a plane must share one cache line across the sub-blocks for that to work (a plane-major table: +10 %).
 // Arithmetic: gmpi_device.hpp (bit-identical to the oracle in strict-order mode).
 #include "gmpi_device.hpp"
 
@@ -247,7 +253,6 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::kLdsBytes];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kOffBytes)));
-    const uint32_t goff_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)smem));
 
     // ---- blockIdx -> band.  XCD x = blockIdx % 8 gets a contiguous run of the bands of EVERY view (group of views that share an MPI): row-major
     //      neighbours share halo rows in one L2, and the XCDs walk the views together (measured 4 % faster than one run of all bands per XCD,
@@ -378,7 +383,11 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         auto issue = [&](const uint4& rl, uint32_t g_off, auto ub) {  // DMA of the plane with record part L = rl into buffer U (this wave's part of its sub-block's box)
             constexpr int U = decltype(ub)::value;
             const int dims = static_cast<int>(rl.z);
-            const u32x4 rsrc = {rl.x, rl.y, 0x80000000u, 0x00020000u};  // raw buffer, num_records 2^31: only the explicit offset below is rejected
+            // raw buffer, num_records 2^31: only the explicit offset below is rejected.  (readfirstlane: the words are wave-uniform and the asm
+            // operand MUST be scalar -- under scalar register pressure the compiler has been seen to keep them in vector registers and to print
+            // those into the "s" operand; the intrinsic is free where they already are scalar)
+            const u32x4 rsrc = {static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rl.x))),
+                                static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(rl.y))), 0x80000000u, 0x00020000u};
             if (dims >= 0) {  // the box lies inside the texture: lanes of the box load, the others are switched off
                 if (dims != dims_cur) {
                     const int nq = dims & 31, rows = dims >> 5;
@@ -478,6 +487,23 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                 q[0] = v0.x, q[1] = v0.y, q[2] = v1.x, q[3] = v1.y, q[4] = v2.x, q[5] = v2.y, q[6] = v3.x, q[7] = v3.y;
             }
         };
+        // Software pipeline of the bf16 default-mode plane step: a batch of 8 taps is ISSUED one batch ahead of the wait that lands it, so the
+        // LDS round trips overlap the wave's own FMAs instead of relying on the other waves of the SIMD.  LDS operations return in order:
+        // with B younger LDS operations issued behind the wanted ones, `lgkmcnt(B)` lands the wanted ones.  Issue and wait are separate asm
+        // statements with the tap registers as operands of both; tools/isa_pipe.py checks that the build has no copy of a tap register
+        // between them (the compiler may copy an asm output as soon as its statement ends).
+        auto taps_issue = [&](auto hb, uint32_t a_tap, uint32_t (&q)[8]) {
+            constexpr int C0 = 2 * decltype(hb)::value;
+            asm volatile("ds_read_u16_d16_hi %0, %8 offset:%9\n\tds_read_u16_d16_hi %1, %8 offset:%10\n\tds_read_u16_d16_hi %2, %8 offset:%11\n\tds_read_u16_d16_hi %3, %8 offset:%12\n\t"
+                         "ds_read_u16_d16_hi %4, %8 offset:%13\n\tds_read_u16_d16_hi %5, %8 offset:%14\n\tds_read_u16_d16_hi %6, %8 offset:%15\n\tds_read_u16_d16_hi %7, %8 offset:%16"
+                         : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+                         : "v"(a_tap), "i"(C0 * kLineBytes), "i"(C0 * kLineBytes + 2), "i"(C0 * kLineBytes + kRowBytes), "i"(C0 * kLineBytes + kRowBytes + 2),
+                           "i"((C0 + 1) * kLineBytes), "i"((C0 + 1) * kLineBytes + 2), "i"((C0 + 1) * kLineBytes + kRowBytes), "i"((C0 + 1) * kLineBytes + kRowBytes + 2));
+        };
+        auto taps_land = [&](auto nb, uint32_t (&q)[8]) {  // wait until at most N LDS operations (all younger than q's) are outstanding
+            constexpr int N = decltype(nb)::value;
+            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : "i"(N));
+        };
         auto pixel = [&](int q, const float4& rf, const float2& rg) {
             Coords c;
             coords(q, rf, rg, c);
@@ -495,48 +521,109 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         };
 
 
-        // One plane step: barrier | loader offset (LDS) and DMA of plane t + 1 | this lane's landed items of plane t folded into the range
-        // check | the pixels | scalar loads of the next step's records (box record of plane t + 2, plane constants of plane t + 1).
-        // (Measured without effect and not kept, profiles/r03_band_variants.txt: the loader offset fetched before the barrier; s_setprio 3
-        //  around the DMA issue.)
+        // One plane step: barrier | DMA of plane t + 1 | this lane's landed items of plane t folded into the range check | the pixels | scalar
+        // loads of the next step's records (box record of plane t + 2, plane constants of plane t + 1).
+        // (Measured and not kept -- profiles/r03_band_variants.txt, r04_band_variants.txt: the loader offset fetched before the barrier;
+        //  s_setprio around the DMA issue or by wave index; the record loads at the top of the step (+5 %: see the head of this file); the range
+        //  check at the end of the step (-1.4 %, superseded by the pipeline); non-temporal DMA (+5 %); the DMA passes spread over the step.)
         uint4 Ln, Fc;      // wave-uniform: scalar registers
         uint32_t rhh_c, gp_c;
+        uint32_t g_off = 0;  // this lane's loader offset: a vector register through the plane loop (round 3 re-read it from LDS behind every barrier)
+#ifdef GMPI_PROF  // (the phase stamps wait for lgkmcnt(0): they would serialise the pipeline they are meant to time)
+        constexpr bool piped = false;
+#else
+        constexpr bool piped = BF && !STRICT && PPT == 2;
+#endif
         auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
             constexpr int U = decltype(ub)::value;
             wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
             GMPI_STAMP(0);
             const uint32_t a_it = sub_base + static_cast<uint32_t>(fresh_tid() & (kSubLanes - 1)) * 16u;
-            const uint32_t a_g = goff_base + (static_cast<uint32_t>(fresh_tid()) << 2);
-            // (loads and their wait in ONE statement: the compiler may copy an asm load's destination as soon as the statement ends)
+            // (loads and their wait in ONE statement unless noted: the compiler may copy an asm load's destination as soon as the statement ends)
             u32x4 cq0, cq1, cq2;
-            uint32_t g_off;
             const bool three_cur = three;  // set by the issue of this plane, one step ago
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g_off) : "v"(a_g));
             if (tt + 1 < D && !abl_noissue) issue(Ln, g_off, ic<1 - U>{});
             GMPI_STAMP(3);
-            if (check_range) {
-                asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                check_fold(cq0), check_fold(cq1);
+            const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
+            // tap address constant of this plane and buffer (an integer below 2^24, exact in fp32)
+            const float2 rg = make_float2(__uint_as_float(rhh_c), static_cast<float>(static_cast<int>(gp_c) + static_cast<int>(tile_base) + U * kBufBytes));
+            auto check_tail = [&]() {  // the third item of a lane (boxes of more than 2 kRPP rows: rare)
                 if (three_cur) {
                     constexpr int kTail = (kSubBytes - 2 * kPassItems * 16) / 16;
                     const uint32_t a_t = sub_base + static_cast<uint32_t>(min(fresh_tid() & (kSubLanes - 1), kTail - 1)) * 16u;
                     asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq2) : "v"(a_t), "i"(U * kBufBytes + 2 * kPassItems * 16));
                     check_fold(cq2);
                 }
-                GMPI_STAMP(2);
-            }
-            const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
-            // tap address constant of this plane and buffer (an integer below 2^24, exact in fp32)
-            const float2 rg = make_float2(__uint_as_float(rhh_c), static_cast<float>(static_cast<int>(gp_c) + static_cast<int>(tile_base) + U * kBufBytes));
-            if (!abl_nocomp) {
+            };
+            if constexpr (piped) {
+                if (abl_nocomp) {
+                    if (check_range) {
+                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                        check_fold(cq0), check_fold(cq1);
+                        check_tail();
+                    }
+                } else {
+                    // LDS operations of the step, in issue order:  c (2 x b128, the range check's read-back) | b0 b1 (pixel 0: channels R G | B A) |
+                    // b2 b3 (pixel 1); every wait but the last leaves the 8 taps of the batch behind it in flight.
+                    uint32_t ta[8], tb[8];
+                    Coords p0, p1;
+                    Footprint f;
+                    float smp[4];
+                    if (check_range) {
+                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                                     : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                    }
+                    coords(0, rf, rg, p0);
+                    taps_issue(ic<0>{}, p0.a_tap, ta);                                        // b0
+                    if (check_range) {
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(cq0), "+v"(cq1) : "i"(8));  // c has landed (b0 may still fly)
+                        check_fold(cq0), check_fold(cq1);
+                        check_tail();
+                    }
+                    taps_issue(ic<1>{}, p0.a_tap, tb);                                        // b1
+                    coords(1, rf, rg, p1);                                                   // (the chain of pixel 1 issues while b0, b1 fly)
+                    asm volatile("" : "+v"(p1.s), "+v"(p1.nw), "+v"(p1.ne), "+v"(p1.sw), "+v"(p1.se), "+v"(p1.a_tap));
+                    taps_land(ic<8>{}, ta);
+                    f.nw = p0.nw, f.ne = p0.ne, f.sw = p0.sw, f.se = p0.se;
+                    smp[0] = bilerp<false>(__uint_as_float(ta[0]), __uint_as_float(ta[1]), __uint_as_float(ta[2]), __uint_as_float(ta[3]), f);
+                    smp[1] = bilerp<false>(__uint_as_float(ta[4]), __uint_as_float(ta[5]), __uint_as_float(ta[6]), __uint_as_float(ta[7]), f);
+                    asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));
+                    taps_issue(ic<0>{}, p1.a_tap, ta);                                        // b2
+                    taps_land(ic<8>{}, tb);
+                    smp[2] = bilerp<false>(__uint_as_float(tb[0]), __uint_as_float(tb[1]), __uint_as_float(tb[2]), __uint_as_float(tb[3]), f);
+                    smp[3] = bilerp<false>(__uint_as_float(tb[4]), __uint_as_float(tb[5]), __uint_as_float(tb[6]), __uint_as_float(tb[7]), f);
+                    blend<false>(A[0], smp[0], smp[1], smp[2], smp[3], p0.s, dots[0]);
+                    asm volatile("" : "+v"(A[0].T), "+v"(A[0].r), "+v"(A[0].g), "+v"(A[0].b), "+v"(A[0].z));
+                    taps_issue(ic<1>{}, p1.a_tap, tb);                                        // b3
+                    taps_land(ic<8>{}, ta);
+                    f.nw = p1.nw, f.ne = p1.ne, f.sw = p1.sw, f.se = p1.se;
+                    smp[0] = bilerp<false>(__uint_as_float(ta[0]), __uint_as_float(ta[1]), __uint_as_float(ta[2]), __uint_as_float(ta[3]), f);
+                    smp[1] = bilerp<false>(__uint_as_float(ta[4]), __uint_as_float(ta[5]), __uint_as_float(ta[6]), __uint_as_float(ta[7]), f);
+                    asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));  // (pins the two samples in front of the last wait)
+                    taps_land(ic<0>{}, tb);
+                    smp[2] = bilerp<false>(__uint_as_float(tb[0]), __uint_as_float(tb[1]), __uint_as_float(tb[2]), __uint_as_float(tb[3]), f);
+                    smp[3] = bilerp<false>(__uint_as_float(tb[4]), __uint_as_float(tb[5]), __uint_as_float(tb[6]), __uint_as_float(tb[7]), f);
+                    blend<false>(A[1], smp[0], smp[1], smp[2], smp[3], p1.s, dots[1]);
+                }
+            } else {
+                if (check_range) {
+                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                    check_fold(cq0), check_fold(cq1);
+                    check_tail();
+                    GMPI_STAMP(2);
+                }
+                if (!abl_nocomp) {
 #pragma unroll
-                for (int q = 0; q < PPT; ++q) {
-                    pixel(q, rf, rg);  // (the LDS round trips of the taps are covered by the other waves of the SIMD: 8 are resident)
-                    GMPI_STAMP(5 + q);
+                    for (int q = 0; q < PPT; ++q) {
+                        pixel(q, rf, rg);  // (the LDS round trips of the taps are covered by the other waves of the SIMD: 8 are resident)
+                        GMPI_STAMP(5 + q);
+                    }
                 }
             }
-            // the records of the next step (both tables are padded by two planes of records: no bounds tests)
+            // The records of the next step (both tables are padded by two planes of records: no bounds tests), BEHIND the last pixel: the waves
+            // that get here first pull the lines into the scalar cache, the workgroup's last wave -- the one the barrier waits for -- hits.
             gp_c = Ln.w;  // (Ln is still the record of plane tt + 1)
             Ln = myrec[static_cast<int64_t>(tt + 2) * kRecStep];
             Fc = mypl[(tt + 1) * kPlU4], rhh_c = mypl[(tt + 1) * kPlU4 + 1].x;
@@ -550,7 +637,8 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
             for (int i = tid; i < 2 * kBufBytes / 16; i += kNT) reinterpret_cast<uint4*>(smem + G::kOffBytes)[i] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();  // (also: the loader offsets are in place)
-        issue(myrec[0], reinterpret_cast<const uint32_t*>(smem)[fresh_tid()], ic<0>{});  // plane 0
+        g_off = reinterpret_cast<const uint32_t*>(smem)[fresh_tid()];
+        issue(myrec[0], g_off, ic<0>{});  // plane 0
         Fc = mypl[0], rhh_c = mypl[1].x, gp_c = myrec[0].w, Ln = myrec[kRecStep];
         for (int t = 0; t < D; t += 2) {
             stage(t, ic<0>{});

@@ -37,4 +37,16 @@ def test_band_kernel_has_no_scratch_and_fits_two_workgroups_per_cu(tmp_path):
         assert 2 * lds <= 160 * 1024, (name, lds)
         # the plane loop: one s_barrier per plane step, the DMA and the taps inside it
         assert body.count("s_barrier") >= 2 and "buffer_load_dwordx4" in body and " lds" in body
+    # the software-pipelined taps (round 4): no instruction may touch the destination of an LDS read that is still in flight
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_pipe", os.path.join(ROOT, "tools", "isa_pipe.py"))
+    isa_pipe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(isa_pipe)
+    piped = 0
+    for name in names:
+        a = asm.index(name + ":")
+        body = asm[a:asm.index(".Lfunc_end", a)].split("\n")
+        assert isa_pipe.check(body, name) == [], name
+        piped += any(re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", l) for l in body)
+    assert piped == 4, piped   # the bf16 default-mode instances (align_corners x range check) are the pipelined ones
     shutil.rmtree(tmp_path, ignore_errors=True)

@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
     p.struct_size = sizeof p; p.rgba_dtype = dt; p.N = N; p.M = N; p.D = D; p.Ht = p.Wt = p.H = p.W = S; p.views_per_mpi = 1;
     p.rgba = vol; p.rgba_stride[0] = (int64_t)D * plane; p.rgba_stride[1] = plane; p.rgba_stride[2] = chan; p.rgba_stride[3] = S; p.rgba_stride[4] = 1;
     p.dhw = d_dhw; p.ray_dir = d_ray; p.eye_pos = d_eye; p.z_dir = d_zd; p.rgb_out = d_rgb; p.depth_out = d_dep; p.status = d_st;
+    if (getenv("KB_PLANE_STRIDE0")) p.rgba_stride[1] = 0;  // (ablation: every plane reads plane 0 -- the volume becomes cache resident, the byte counts stay)
     {  // workspace for the kernels that want one (GMPI_VARIANT_BAND)
         auto wsb = (uint64_t (*)(const GmpiRenderParams*))dlsym(h, "gmpi_render_workspace_bytes");
         p.flags = GMPI_FLAG_ALIGN_CORNERS;
@@ -95,6 +96,7 @@ int main(int argc, char** argv) {
         if (v.size() > 2 && v.substr(v.size() - 2) == ":s") strict = true, v = v.substr(0, v.size() - 2);
         p.variant = v == "gather" ? 1 : v == "lds" ? 2 : v == "wave" ? 3 : v == "dma" ? 4 : v == "band" ? 5 : 0;
         p.flags = GMPI_FLAG_ALIGN_CORNERS | GMPI_FLAG_OUT_PM1 | GMPI_FLAG_CHECK_LAST_PLANE | GMPI_FLAG_CHECK_RANGE | (strict ? GMPI_FLAG_STRICT_ORDER : 0);
+        if (getenv("KB_NOCHECK")) p.flags &= ~static_cast<unsigned>(GMPI_FLAG_CHECK_RANGE);  // (A/B: what the fused [0,1] test costs)
         {  // the hint a host that knows the poses gives (MPIRenderer.render does): every camera axis within 0.2 rad of the MPI normal
             bool frontal = true;
             for (int n = 0; n < N; ++n) frontal = frontal && zd[n * 3 + 2] >= 0.98006658f;  // cos(0.2)

@@ -62,8 +62,30 @@ __global__ void band_kernel(const uint16_t* __restrict__ vol, int bw, int bh, in
 #pragma unroll
         for (int r = 0; r < NP; ++r) dma16(g_off[r], rsrc, dst + r * stride, mask[r]);
     };
-    for (int u = 0; u < pf; ++u) issue(u);
     uint32_t acc = 0;
+    if (order == 3) {  // ring of 4 slots, TWO planes per barrier: planes k + 2, k + 3 are in flight while k, k + 1 are read (pf must be 3: 4 buffers)
+        issue(0), issue(1);
+        for (int k = 0; k < D; k += 2) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (k + 2 < D) issue(k + 2), issue(k + 3);
+            acc += *reinterpret_cast<volatile uint32_t*>(smem + (k % 4) * buf_bytes + tid * 4);
+            acc += *reinterpret_cast<volatile uint32_t*>(smem + ((k + 1) % 4) * buf_bytes + tid * 4);
+        }
+        if (acc == 0x12345678u) sink[0] = acc;
+        return;
+    }
+    for (int u = 0; u < pf; ++u) issue(u);
+    if (pf == 3) {  // three planes ahead, one barrier per plane, partial waits
+        for (int k = 0; k < D; ++k) {
+            if (k + 2 < D) { if (NP == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else if (NP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (k + pf < D) issue(k + pf);
+            acc += *reinterpret_cast<volatile uint32_t*>(smem + (k % (pf + 1)) * buf_bytes + tid * 4);
+        }
+        if (acc == 0x12345678u) sink[0] = acc;
+        return;
+    }
     for (int k = 0; k < D; ++k) {
         if (pf == 2 && k + 1 < D) { if (NP == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else if (NP == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
