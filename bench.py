@@ -139,15 +139,197 @@ def cpu_baseline(preset, S, D, dtype, budget_s=20.0):
     return res
 
 
+def run_video(a, dev, rank, world, use_dist):
+    """--workload video: the camera-path loop of the reference's video script on the GPU, in its own shape -- ONE MPI (512^2 x 96, fp32), one
+    view per `render()` call with `horizontal_mean = angle`, std 0, and a device-to-host copy + uint8 conversion per view
+    (eval/vis/render_video.py:95-130, `generate_img`) -- next to the batched driver (`ViewBatchDriver.render_path`: 8 views per launch, uint8
+    epilogue on the device, one copy at the end).  A "step" = one pass over this rank's share of the 64-view path (BASELINE config 4)."""
+    import numpy as np
+    import ml_gmpi_amd
+    S, D, n_path = 512, 96, 64
+    r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=D, device=dev, kernel_variant=a.variant, on_out_of_plane="raise")
+    g = torch.Generator(device=dev).manual_seed(4000)
+    rgba = torch.rand((1, D, 4, S, S), device=dev, generator=g)
+    rgba[:, -1, 3] = 1.0
+    angles = np.linspace(0.5, -0.5, n_path).tolist()[rank::world]
+    near, far = r.plane_min_d, r.plane_max_d
+
+    t_parts = [0.0, 0.0]   # seconds inside render() | until both frames are on the host (the rest of a pass is the script's own numpy)
+
+    def per_call_pass():  # render_video.py:95-130, line by line
+        frames = []
+        for ang in angles:
+            t_a = time.perf_counter()
+            img, depth, _, _ = r.render(rgba, S, S, horizontal_mean=ang, horizontal_std=0.0, vertical_mean=0.0, vertical_std=0.0,
+                                        assert_not_out_of_last_plane=True)
+            t_b = time.perf_counter()
+            img, depth = img.permute(0, 2, 3, 1).squeeze().cpu(), depth.permute(0, 2, 3, 1).squeeze().cpu()
+            t_c = time.perf_counter()
+            t_parts[0] += t_b - t_a
+            t_parts[1] += t_c - t_b
+            img = img.numpy()
+            img = ((img + 1) / 2.0 * 255).astype(np.uint8)
+            dm = depth.numpy()
+            dm = (np.clip((dm - near) / (far - near), 0, 1)[..., None] * 255).astype(np.uint8)
+            frames.append((img, dm))
+        return frames
+
+    drv = ml_gmpi_amd.ViewBatchDriver(r, batch=8)
+
+    def batched_pass():
+        res = drv.render_path(rgba, S, angles, [0.0] * len(angles), to_uint8=True, depth_range=(near, far))
+        return res["img8"].cpu(), res["dep8"].cpu()
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(max(a.warmup, 1)):
+            per_call_pass(); batched_pass()
+        fence(); t0 = time.perf_counter()
+        t_parts[0] = t_parts[1] = 0.0
+        for _ in range(a.steps):
+            per_call_pass()
+        fence(); t_call = time.perf_counter() - t0
+        in_render, to_host = t_parts[0], t_parts[1]
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            batched_pass()
+        fence(); t_batch = time.perf_counter() - t0
+        a_frames, b_frames = per_call_pass(), batched_pass()
+    same = all(np.array_equal(f[0], b_frames[0][i].numpy()) for i, f in enumerate(a_frames))  # the two paths give the same uint8 frames
+    t = torch.tensor([t_call, t_batch], device=dev, dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_call, t_batch = float(t[0]), float(t[1])
+    if rank == 0:
+        views = n_path * a.steps
+        line = {"metric": "Mpix*planes/s", "value": round(views * S * S * D / t_call / 1e6, 1), "unit": "Mpix*planes/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": round(t_call / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "FFHQ512-shaped video path: 512x512, 96 planes, 64 camera-path views of ONE MPI, one view per render() call + "
+                                       ".cpu() per view (render_video.py:95-130)", "name": "video", "H": S, "W": S, "planes": D, "rgba_storage": "f32",
+                           "variant": a.variant, "parallelism": f"views of the path strided over {world} rank(s)"},
+                "views_per_s": round(views / t_call, 1), "ms_per_view": round(t_call / views * world * 1e3, 4),
+                "per_view_ms": {"render_call_host": round(in_render / (len(angles) * a.steps) * 1e3, 4), "sync_and_copy_to_host": round(to_host / (len(angles) * a.steps) * 1e3, 4),
+                                "script_numpy": round((t_call - in_render - to_host) / (len(angles) * a.steps) * 1e3, 4),
+                                "what": "render(): host time of the call | .cpu() x 2: waits for the kernel, copies 4 MB | the script's own uint8 conversion (numpy)"},
+                "render_and_copy_views_per_s": round(len(angles) * a.steps * world / (in_render + to_host), 1),
+                "batched_driver": {"views_per_s": round(views / t_batch, 1), "ms_per_view": round(t_batch / views * world * 1e3, 4), "batch": 8,
+                                   "what": "ViewBatchDriver.render_path: 8 views per launch, uint8 epilogue on the device, one copy per pass"},
+                "frames_identical": bool(same), "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+PARITY_BAR = 1e-5  # BASELINE.json north_star: "within 1e-5 fp32" (colour on the [-1, 1] scale of MPIRenderer.render, depth in scene units)
+
+
+def parity_block(r, rgba, dhw, ray, eye, zd, vpm, want_T, S):
+    """The bench's OWN launch (same tensors, same flags, GMPI_VARIANT as timed) rendered once more in strict-order mode and once in default
+    mode, outside the timed region, and compared with the CPU oracle on three 64 x 64 ray windows of every view (the oracle needs minutes
+    per full 1024^2 x 96 view).  Strict mode must be bit-identical, default mode within PARITY_BAR.  """
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle
+    from ml_gmpi_amd import _lib
+    oracle.build()
+    dev = rgba.device
+    n_views = ray.shape[0]
+    outs = {}
+    was = r.mpi.strict_order
+    for strict in (True, False):
+        r.mpi.strict_order = strict
+        st = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        outs[strict] = r.mpi.render_views(rgba, dhw, ray, eye, zd, views_per_mpi=vpm, check_last_plane=True, out_pm1=True,
+                                          want_transmittance=True, status=st, defer_status=True)
+        r.mpi.raise_on_status(st)
+    r.mpi.strict_order = was
+    w = min(64, S)
+    wins = sorted({(0, 0), (S - w, S - w), (max(S // 2 - w // 2, 0), min(S // 2 + 7, S - w))})
+    res = dict(strict_bit_exact=True, max_abs_err_color=0.0, max_abs_err_depth=0.0, max_abs_err_T=0.0, bar=PARITY_BAR,
+               windows=f"{len(wins)} windows of {w}x{w} pixels per view x {n_views} views vs oracle/mpi_oracle.c", color_scale="[-1, 1]")
+    vol_cache = {}
+    for n in range(n_views):
+        m = n // vpm
+        if m not in vol_cache:
+            vol_cache.clear()
+            vol_cache[m] = rgba[m:m + 1].float().cpu().numpy()   # exact upcast of the stored values (mpi_renderer.py:446)
+        vol = vol_cache[m]
+        for (y0, x0) in wins:
+            win = ray[n:n + 1, :, y0:y0 + w, x0:x0 + w].contiguous().cpu()
+            orc = oracle.render(vol, dhw[m:m + 1].cpu(), win, eye[n:n + 1].cpu(), zd[n:n + 1].cpu(), threads=True)
+            ref = dict(color=np.float32(2.0) * orc["color"] - np.float32(1.0), depth=orc["depth"], T=orc["T"])   # mpi_renderer.py:467
+            for key in ("color", "depth", "T"):
+                got_s = outs[True][key][n:n + 1, :, y0:y0 + w, x0:x0 + w].cpu().numpy()
+                got_d = outs[False][key][n:n + 1, :, y0:y0 + w, x0:x0 + w].cpu().numpy()
+                if not np.array_equal(got_s, ref[key]):
+                    res["strict_bit_exact"] = False
+                    res.setdefault("strict_max_abs_err", 0.0)
+                    res["strict_max_abs_err"] = max(res["strict_max_abs_err"], float(np.abs(got_s - ref[key]).max()))
+                k = "max_abs_err_" + key
+                res[k] = max(res[k], float(np.abs(got_d - ref[key]).max()))
+    res["ok"] = bool(res["strict_bit_exact"] and res["max_abs_err_color"] <= PARITY_BAR and res["max_abs_err_depth"] <= PARITY_BAR
+                     and res["max_abs_err_T"] <= PARITY_BAR)
+    if not want_T:
+        res["note"] = "T compared as well (the timed launch does not write it)"
+    for k in ("max_abs_err_color", "max_abs_err_depth", "max_abs_err_T"):
+        res[k] = float(f"{res[k]:.3e}")
+    return res
+
+
+def pose_sweep(r, rgba, dhw, n_views, vpm, want_T, S, draws, out, status, seed0=100):
+    """The timed launch under `draws` seeded draws of the renderer's pose distribution (curriculums.py:109-116 / gmpi.yml:91-96 through
+    MPIRenderer.sample_cam_poses): the headline number is ONE draw (seed 3); this is the distribution.  Per draw: 3 event-timed launches
+    behind one warm-up, the median counts.  `views_off_band`: views the band kernel handed to the tile kernel (workspace header words)."""
+    import statistics
+    from ml_gmpi_amd import hip_mpi
+    dev = rgba.device
+    ms, off_band, n_total = [], 0, 0
+    bw = 256 if rgba.dtype == torch.bfloat16 else 128
+    n_bands_view = ((S + bw - 1) // bw) * ((S + 7) // 8)
+    for d in range(draws):
+        torch.manual_seed(seed0 + d)
+        cam = r.sample_cam_poses(n_views, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+        ray, eye, zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+
+        def step():
+            r.mpi.render_views(rgba, dhw, ray, eye, zd, views_per_mpi=vpm, check_last_plane=True, out_pm1=True,
+                               want_transmittance=want_T, status=status, defer_status=True, out=out)
+        step()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for e0, e1 in evs:
+            e0.record(); step(); e1.record()
+        torch.cuda.synchronize(dev)
+        ms.append(statistics.median(e0.elapsed_time(e1) for e0, e1 in evs))
+        ws = next(iter(hip_mpi._WORKSPACES.values()), None) if hip_mpi._WORKSPACES else None
+        if ws is not None and ws.numel() >= 4 * n_bands_view * n_views and r.mpi.variant == "auto":
+            hdr = ws[:4 * n_bands_view * n_views].view(torch.int32).view(n_views, n_bands_view)
+            off_band += int((hdr != 0).any(dim=1).sum())
+            n_total += n_views
+    r.mpi.raise_on_status(status)
+    q = sorted(ms)
+    return dict(draws=draws, seeds=f"{seed0}..{seed0 + draws - 1}", mean_ms=round(sum(ms) / len(ms), 4), p50_ms=round(q[len(q) // 2], 4),
+                p90_ms=round(q[min(int(0.9 * len(q)), len(q) - 1)], 4), worst_ms=round(q[-1], 4), best_ms=round(q[0], 4),
+                views_off_band_share=None if n_total == 0 else round(off_band / n_total, 4))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["video"])
     ap.add_argument("--variant", default="auto", choices=["auto", "gather", "lds", "wave", "dma", "band"])
     ap.add_argument("--strict", action="store_true", help="strict-order arithmetic (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed launch (rank 0, outside the timed region)")
+    ap.add_argument("--pose-draws", type=int, default=32, help="draws of the pose distribution in the `pose_sweep` block (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="untimed render launches for this long before the W warm-up steps: a GPU coming from idle needs ~0.1 s to reach "
@@ -172,6 +354,8 @@ def main():
     import ml_gmpi_amd
     from ml_gmpi_amd import _lib
 
+    if a.workload == "video":
+        return run_video(a, dev, rank, world, use_dist)
     preset, S, D, n_views, dtype, want_T, desc = WORKLOADS[a.workload]
     r = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=a.variant, strict_order=a.strict,
                                   on_out_of_plane="raise")
@@ -235,13 +419,20 @@ def main():
         # end-to-end MPIRenderer.render(): pose sampling on the host + rays + launch + status sync
         r.render(rgba, S, S, views_per_mpi=vpm)  # warm-up of the pose/ray path (first call loads its kernels)
         e2e = []
-        for _ in range(7):  # median: an occasional 80-ms allocator/runtime hiccup would dominate a mean
+        for _ in range(24):  # every call draws fresh poses: the mean and the worst call are reported (a median would hide the tilted draws)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             r.render(rgba, S, S, views_per_mpi=vpm)
             torch.cuda.synchronize(dev)
             e2e.append((time.perf_counter() - t1) * 1e3)
-        e2e_ms = sorted(e2e)[len(e2e) // 2]
+        e2e_ms, e2e_max_ms = sum(e2e) / len(e2e), max(e2e)
+        # ... and back to back, one sync at the end (a driver loop: the host runs ahead of the device, status checks lag by a call)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(24):
+            r.render(rgba, S, S, views_per_mpi=vpm)
+        torch.cuda.synchronize(dev)
+        e2e_b2b_ms = (time.perf_counter() - t1) * 1e3 / 24
         # the same with the poses of the calls drawn ahead of time (MPIRenderer.prefetch_poses): what is left between two
         # launches is the ray kernel, the marshalling of the parameter struct and the status read-back
         r.prefetch_poses(8, n_views)
@@ -254,6 +445,10 @@ def main():
             torch.cuda.synchronize(dev)
             e2e_pre.append((time.perf_counter() - t1) * 1e3)
         e2e_pre_ms = sorted(e2e_pre)[len(e2e_pre) // 2]
+        ml_gmpi_amd.flush_status()  # (render() checks its status bits a call late: the last ones now)
+        sweep = None
+        if a.pose_draws > 0 and a.workload != "cfg4":  # (config 4's poses are a fixed yaw sweep, not a draw)
+            sweep = pose_sweep(r, rgba, dhw, n_views, vpm, want_T, S, a.pose_draws, out, status)
         # final gather of the finished frames (the only collective of the job)
         gather_ms = None
         if use_dist:
@@ -341,16 +536,25 @@ def main():
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": abytes,
                          # conservative companion: only the texel boxes the views actually touch
                          "footprint_bytes_per_launch": fbytes, "frac_footprint": round(fbytes / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "e2e_render_ms": round(e2e_ms, 3), "e2e_render_prefetched_poses_ms": round(e2e_pre_ms, 3), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "e2e_render_ms": round(e2e_ms, 3), "e2e_render_max_ms": round(e2e_max_ms, 3), "e2e_render_back_to_back_ms": round(e2e_b2b_ms, 3),
+            "e2e_render_prefetched_poses_ms": round(e2e_pre_ms, 3), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "pose_sweep": sweep,
         }
+        if not a.no_parity:
+            line["parity"] = parity_block(r, rgba, dhw, ray, eye, zd, vpm, want_T, S)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(preset, S, D, dtype, a.cpu_budget)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
+        parity_failed = bool(line.get("parity")) and not line["parity"]["ok"]
+    else:
+        parity_failed = False
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: the timed launch does not match the oracle (see `parity` in the line above)")
 
 
 if __name__ == "__main__":

@@ -90,8 +90,18 @@ def library_path() -> str:
     return _SO
 
 
+_STAMP = os.path.join(_PKG, "csrc", ".built_from")
+
+
 def build_extension(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 with hipcc (ml-gmpi_amd/csrc/Makefile). Returns the .so path."""
+    """Compile the HIP sources for gfx950 with hipcc (ml-gmpi_amd/csrc/Makefile). Returns the .so path.
+
+    `make` trusts time stamps; a snapshot can carry objects whose time stamps are newer than sources they were not built from.  So a
+    successful build leaves the hash of the sources it compiled in csrc/.built_from, and a build that finds another hash there (or none)
+    recompiles everything (`make -B`), as does force=True or GMPI_BUILD_FORCE=1 in the environment."""
+    want = source_hash() + " " + _makefile_hash()
+    have = open(_STAMP).read().strip() if os.path.isfile(_STAMP) else None
+    force = force or os.environ.get("GMPI_BUILD_FORCE", "") not in ("", "0") or have != want or not os.path.isfile(_SO)
     cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j4"] + (["-B"] if force else [])
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
@@ -99,7 +109,26 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
         print(res.stderr)
     if res.returncode != 0 or not os.path.isfile(_SO):
         raise GmpiError("building libgmpi_render.so failed:\n" + res.stderr[-4000:])
+    with open(_STAMP, "w") as f:
+        f.write(want + "\n")
     return _SO
+
+
+def _makefile_hash() -> str:
+    import hashlib
+    with open(os.path.join(_PKG, "csrc", "Makefile"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:8]
+
+
+def build_report() -> str:
+    """One line per object: what build() prints so that a log shows which sources the library in use was built from."""
+    import glob
+    import time
+    rows = [f"sources {source_hash()} (csrc/*.hip, *.hpp, include/gmpi_render.h); stamp {open(_STAMP).read().strip() if os.path.isfile(_STAMP) else None}"]
+    for f in sorted(glob.glob(os.path.join(_PKG, "csrc", "*.o"))) + [_SO]:
+        if os.path.isfile(f):
+            rows.append(f"  {os.path.relpath(f, os.path.dirname(_PKG)):44s} {os.path.getsize(f):9d} B  {time.strftime('%Y-%m-%d %H:%M:%S', time.localtime(os.path.getmtime(f)))}")
+    return "\n".join(rows)
 
 
 def load_library():

@@ -10,6 +10,8 @@ folded into a status bit), no min/max passes (mpi.py:185-187).
 There is no CPU/PyTorch fallback: tensors must live on a ROCm device and the HIP library must be
 built, otherwise this raises.
 """
+import atexit
+import collections
 import contextlib
 import ctypes
 import sys
@@ -49,6 +51,65 @@ def _own_status(dev: torch.device, stream: int) -> torch.Tensor:
     if st is None:
         st = _STATUS[key] = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
     return st
+
+
+# Lagged status (defer_status="lag": the default of `MPIRenderer.render`).  The assertions of a render are status bits the kernel ORs into a
+# few words; reading them back with `.item()` blocks the host until the kernel has finished -- the whole host cost of a call (round 3:
+# profiles/r03_host_render.txt).  In lagged mode every call gets its own status slot out of a small ring, copies it to pinned host memory
+# behind the kernel (asynchronously) and records an event; the slot is LOOKED AT when a later call on that stream finds its event complete
+# (or the ring is full, or `flush_status()` is called -- `atexit` does).  An assertion therefore surfaces one or a few calls late, with the
+# diagnostics of the call that tripped it; results are unaffected.
+_RING_SLOTS = 16
+_RINGS = {}
+
+
+class _StatusRing:
+    def __init__(self, dev: torch.device):
+        self.dev_words = torch.zeros((_RING_SLOTS, _lib.STATUS_WORDS), dtype=torch.int32, device=dev)
+        self.host_words = torch.zeros((_RING_SLOTS, _lib.STATUS_WORDS), dtype=torch.int32).pin_memory()
+        self.free = collections.deque(range(_RING_SLOTS))
+        self.pending = collections.deque()   # (slot, event, mpi, params, keep, c2w_mat, sphere_c) in launch order
+
+    def retire(self, block: bool) -> None:
+        """Looks at every pending slot whose event has completed (block: waits for the oldest first)."""
+        while self.pending:
+            slot, ev, mpi, params, keep, c2w_mat, sphere_c = self.pending[0]
+            if block:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            block = False
+            self.pending.popleft()
+            self.free.append(slot)
+            if int(self.host_words[slot, 0]) != 0:
+                word_tensor = self.host_words[slot].clone()
+                self.dev_words[slot].zero_()      # (a slot that tripped: clean for its next user)
+                self.host_words[slot].zero_()
+                mpi.raise_on_status(word_tensor, params=params, keep=keep, c2w_mat=c2w_mat, sphere_c=sphere_c)
+
+    def acquire(self) -> int:
+        self.retire(block=False)
+        if not self.free:
+            self.retire(block=True)
+        return self.free.popleft()
+
+
+def _ring(dev: torch.device, stream: int) -> _StatusRing:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+    ring = _RINGS.get(key)
+    if ring is None:
+        ring = _RINGS[key] = _StatusRing(dev)
+    return ring
+
+
+def flush_status() -> None:
+    """Waits for every render launched with a lagged status and raises what they asserted (see `_StatusRing`)."""
+    for ring in list(_RINGS.values()):
+        while ring.pending:
+            ring.retire(block=True)
+
+
+atexit.register(flush_status)
 
 
 def _on_device(dev: Optional[torch.device]):
@@ -158,8 +219,10 @@ class MPI(nn.Module):
         rgba [M,D,4,Ht,Wt] (f32/bf16/f16, any outer strides, innermost contiguous), dhw [M,D,3],
         ray_dir [N,3,H,W], eye_pos [N,3], z_dir [N,3].  View n samples MPI `view_to_mpi[n]`; without it,
         `views_per_mpi` (an int or one count per MPI) gives the reference's grouping.
-        Returns dict(color, depth[, T], status).  With `defer_status` the status word is not read back
-        (no host sync); call `raise_on_status` later.
+        Returns dict(color, depth[, T], status).  With `defer_status=True` the status word is not read back
+        (no host sync); call `raise_on_status` later.  `defer_status="lag"`: the call neither blocks nor leaves the check to the caller --
+        its status travels to pinned host memory behind the kernel and is looked at by a later call on the same stream, by
+        `flush_status()` or at interpreter exit (see `_StatusRing`).
         """
         if torch.is_grad_enabled() and dhw.requires_grad:
             raise NotImplementedError("no gradient flows to the plane geometry (the reference computes the grid under "
@@ -217,7 +280,15 @@ class MPI(nn.Module):
             T = out.get("T")
             if T is None:
                 T = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
-        if status is None:
+        lag = defer_status == "lag" and status is None and on_device and not _in_autograd_fn
+        if defer_status == "lag" and not lag:
+            defer_status = False   # (a caller-owned status tensor, the autograd bridge, the recorder library: read back at once)
+        ring = slot = None
+        if lag:
+            ring = _ring(dev, torch.cuda.current_stream(dev).cuda_stream)
+            slot = ring.acquire()   # (raises here what an earlier call asserted)
+            status = ring.dev_words[slot]
+        elif status is None:
             if on_device and not defer_status and not _in_autograd_fn:
                 status = _own_status(dev, torch.cuda.current_stream(dev).cuda_stream)
             else:
@@ -267,7 +338,12 @@ class MPI(nn.Module):
         res = dict(color=color, depth=depth, T=T, status=status)
         if _in_autograd_fn:  # what the backward needs to rebuild the launch
             res["_bwd"] = (p, (rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi))
-        if not defer_status:
+        if lag:
+            ring.host_words[slot].copy_(status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            ring.pending.append((slot, ev, self, p, (rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi), c2w_mat, sphere_c))
+        elif not defer_status:
             self.raise_on_status(status, params=p, keep=(rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi),
                                  c2w_mat=c2w_mat, sphere_c=sphere_c)
         return res
@@ -277,8 +353,8 @@ class MPI(nn.Module):
         word = int(status[0].item())  # the only host sync of a render call
         if word == 0:
             return
-        if any(status is st for st in _STATUS.values()):
-            status.zero_()  # (the shared words of this device and stream: clean for the next call)
+        if status.is_cuda:
+            status.zero_()  # (the shared words of this device and stream, or a caller's that a later call ORs into: clean for the next call)
         if word & _lib.STATUS_BAD_VIEW_INDEX:
             raise IndexError("view_to_mpi holds an index outside [0, #mpi)")
         if word & _lib.STATUS_RGBA_RANGE:
@@ -291,7 +367,7 @@ class MPI(nn.Module):
             msg = "Ray goes out of the last plane"
             if params is not None:
                 lib = _lib.load_library()
-                dev = status.device
+                dev = keep[0].device if keep is not None else status.device   # (a lagged status word arrives as a host tensor)
                 uv = torch.empty((params.N, 4), dtype=torch.float32, device=dev)
                 with torch.cuda.device(dev):
                     _lib.check(lib.gmpi_last_plane_uv_minmax_launch(ctypes.byref(params), uv.data_ptr(),

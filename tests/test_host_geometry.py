@@ -192,3 +192,25 @@ def test_look_ahead_poses_are_the_poses_the_calls_would_have_drawn():
         torch.manual_seed(5)
         b = r.sample_cam_poses(2, 0.0, 0.1, 0.0, 0.1, True)
         assert all(torch.equal(x, y) for x, y in zip(w, b[:3]))
+
+
+def test_zero_deviation_draws_are_cached_and_identical_to_the_general_path():
+    """render_video.py:95-130 calls render(h_mean=angle, h_stddev=0) per view: a "random" draw whose result is the mean itself.  The renderer
+    serves such requests from a per-request cache -- same pose bits and the same generator state afterwards as the general path
+    (poses.gen_sphere_path with flag_rnd=True, itself pinned to the reference by golden/geometry.npz), first call and cached call alike."""
+    import ml_gmpi_amd
+    from ml_gmpi_amd.poses import gen_sphere_path
+    r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=8, device=torch.device("cpu"), ray_backend="torch")
+    for ang, vm, B in ((0.37, 0.0, 1), (-0.5, 0.1, 3), (0.37, 0.0, 1)):   # (the third request repeats the first: a cache hit)
+        torch.manual_seed(77)
+        c2w_ref, yaws_ref, pitches_ref = gen_sphere_path(
+            n_cams=B, sphere_center=r.sphere_center, sphere_r=r.sphere_r, yaw_mean=ang, yaw_std=0.0, pitch_mean=vm, pitch_std=0.0,
+            n_truncated_stds=r.cam_pose_n_truncated_stds, flag_rnd=True, sample_method=r.cam_sample_method)
+        state_ref = torch.get_rng_state()
+        torch.manual_seed(77)
+        yaws, pitches, c2w, angles = r._draw_poses(B, ang, 0.0, vm, 0.0, True)
+        assert torch.equal(torch.get_rng_state(), state_ref)
+        assert torch.equal(yaws, yaws_ref) and torch.equal(pitches, pitches_ref)
+        assert np.array_equal(c2w.numpy(), torch.FloatTensor(c2w_ref).numpy())
+        assert torch.equal(angles, torch.cat([pitches_ref, yaws_ref], -1))
+    assert len(r._det_poses) == 2
