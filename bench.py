@@ -227,6 +227,71 @@ def run_video(a, dev, rank, world, use_dist):
         dist.destroy_process_group()
 
 
+class _DryLibrary:
+    """--dry-run: stands in for libgmpi_render.so (every launch is counted and returns GMPI_OK): the rank logic of this script -- argument
+    parsing, per-rank seeding and sharding, barriers, all_reduce(MAX), all_gather_into_tensor, the rank-0 line -- runs on CPU tensors under
+    `gloo` at any world size (tests/test_bench_ranks_gloo.py: 8 ranks).  No number of such a run means anything."""
+    records_only = True
+
+    def __init__(self):
+        self.launches = 0
+
+    def gmpi_mpi_render_launch(self, pref, stream):
+        self.launches += 1
+        return 0
+
+    def gmpi_rgba_range_check_launch(self, *args):
+        return 0
+
+    def gmpi_render_workspace_bytes(self, pref):
+        return 0
+
+
+class _WallEvent:
+    """torch.cuda.Event's two methods on the host clock (dry runs)."""
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def numa_pin(local_rank: int, enable: bool):
+    """Pins this rank's host threads to the cores of the NUMA node its GPU hangs off (sysfs: /sys/class/drm/card*/device/numa_node through the
+    device's PCI address; `rocm-smi --showtoponuma` shows the same).  One process per GPU otherwise floats over all sockets and its launch
+    latency depends on where the scheduler left it.  Returns a description for the bench line; never fails the run."""
+    if not enable:
+        return None
+    try:
+        pci = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
+        if pci is None:
+            import ctypes
+            buf = ctypes.create_string_buffer(64)
+            hip = ctypes.CDLL("libamdhip64.so")
+            if hip.hipDeviceGetPCIBusId(buf, 64, local_rank) != 0:
+                return "unavailable (hipDeviceGetPCIBusId failed)"
+            pci = buf.value.decode()
+        node_file = f"/sys/bus/pci/devices/{pci.lower()}/numa_node"
+        node = int(open(node_file).read().strip())
+        if node < 0:
+            return f"gpu {local_rank} ({pci}): no NUMA affinity reported"
+        cpus = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
+        ids = set()
+        for part in cpus.split(","):
+            lo, _, hi = part.partition("-")
+            ids.update(range(int(lo), int(hi or lo) + 1))
+        ids &= os.sched_getaffinity(0)
+        if not ids:
+            return f"gpu {local_rank} ({pci}): node {node} has no allowed cpu"
+        os.sched_setaffinity(0, ids)
+        return f"gpu {local_rank} ({pci}) -> NUMA node {node}, {len(ids)} cpus ({cpus})"
+    except Exception as e:  # noqa: BLE001 -- a missing sysfs entry must not cost the bench line
+        return f"unavailable ({type(e).__name__}: {e})"
+
+
 PARITY_BAR = 1e-5  # BASELINE.json north_star: "within 1e-5 fp32" (colour on the [-1, 1] scale of MPIRenderer.render, depth in scene units)
 
 
@@ -325,9 +390,12 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["video"])
-    ap.add_argument("--variant", default="auto", choices=["auto", "gather", "lds", "wave", "dma", "band"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "gather", "lds", "wave", "band"])
     ap.add_argument("--strict", action="store_true", help="strict-order arithmetic (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: CPU tensors, gloo, launches counted instead of executed -- exercises the rank logic only")
+    ap.add_argument("--dry-size", type=int, default=64, help="image / texture size of a --dry-run (the volumes live in host memory)")
+    ap.add_argument("--numa-pin", action="store_true", help="pin each rank's host threads to the NUMA node of its GPU (mapping printed in the line)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed launch (rank 0, outside the timed region)")
     ap.add_argument("--pose-draws", type=int, default=32, help="draws of the pose distribution in the `pose_sweep` block (0 = skip)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -343,22 +411,42 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if use_dist:
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+    dry = a.dry_run
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path; --dry-run exercises the rank logic only)")
+    if dry:
+        dev = torch.device("cpu")
+        if use_dist:
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if use_dist:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    pinned = None if dry else numa_pin(local_rank, a.numa_pin)
 
     import ml_gmpi_amd
     from ml_gmpi_amd import _lib
 
+    if dry:
+        dry_lib = _DryLibrary()
+        _lib.load_library = lambda: dry_lib
+        a.no_parity, a.pose_draws, a.no_cpu_baseline, a.prewarm_ms = True, 0, True, 0.0
+    Event = _WallEvent if dry else torch.cuda.Event
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize(dev)
+
     if a.workload == "video":
+        assert not dry, "--dry-run covers the render workloads"
         return run_video(a, dev, rank, world, use_dist)
     preset, S, D, n_views, dtype, want_T, desc = WORKLOADS[a.workload]
+    if dry:
+        S, D = a.dry_size, min(D, 8)
     r = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=a.variant, strict_order=a.strict,
-                                  on_out_of_plane="raise")
+                                  on_out_of_plane="raise", **({"ray_backend": "torch"} if dry else {}))
     r.set_cam(r.cam_fov, S, S)
     # ---- synthetic inputs, resident in HBM --------------------------------------------------------
     n_mpis = 1 if a.workload == "cfg4" else n_views
@@ -392,10 +480,10 @@ def main():
                            want_transmittance=want_T, status=status, defer_status=True, out=out)
 
     def fence():
-        torch.cuda.synchronize(dev)
+        sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
     with torch.no_grad():
         if a.prewarm_ms > 0:  # clock ramp (untimed, before the W warm-up steps)
@@ -403,10 +491,10 @@ def main():
             while (time.perf_counter() - t_pre) * 1e3 < a.prewarm_ms:
                 for _ in range(8):
                     step()
-                torch.cuda.synchronize(dev)
+                sync()
         for _ in range(a.warmup):
             step()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        ev = [(Event(enable_timing=True), Event(enable_timing=True)) for _ in range(a.steps)]
         fence()
         t0 = time.perf_counter()
         for i in range(a.steps):
@@ -420,18 +508,18 @@ def main():
         r.render(rgba, S, S, views_per_mpi=vpm)  # warm-up of the pose/ray path (first call loads its kernels)
         e2e = []
         for _ in range(24):  # every call draws fresh poses: the mean and the worst call are reported (a median would hide the tilted draws)
-            torch.cuda.synchronize(dev)
+            sync()
             t1 = time.perf_counter()
             r.render(rgba, S, S, views_per_mpi=vpm)
-            torch.cuda.synchronize(dev)
+            sync()
             e2e.append((time.perf_counter() - t1) * 1e3)
         e2e_ms, e2e_max_ms = sum(e2e) / len(e2e), max(e2e)
         # ... and back to back, one sync at the end (a driver loop: the host runs ahead of the device, status checks lag by a call)
-        torch.cuda.synchronize(dev)
+        sync()
         t1 = time.perf_counter()
         for _ in range(24):
             r.render(rgba, S, S, views_per_mpi=vpm)
-        torch.cuda.synchronize(dev)
+        sync()
         e2e_b2b_ms = (time.perf_counter() - t1) * 1e3 / 24
         # the same with the poses of the calls drawn ahead of time (MPIRenderer.prefetch_poses): what is left between two
         # launches is the ray kernel, the marshalling of the parameter struct and the status read-back
@@ -439,10 +527,10 @@ def main():
         r.render(rgba, S, S, views_per_mpi=vpm)
         e2e_pre = []
         for _ in range(7):
-            torch.cuda.synchronize(dev)
+            sync()
             t1 = time.perf_counter()
             r.render(rgba, S, S, views_per_mpi=vpm)
-            torch.cuda.synchronize(dev)
+            sync()
             e2e_pre.append((time.perf_counter() - t1) * 1e3)
         e2e_pre_ms = sorted(e2e_pre)[len(e2e_pre) // 2]
         ml_gmpi_amd.flush_status()  # (render() checks its status bits a call late: the last ones now)
@@ -504,7 +592,7 @@ def main():
         vol_bytes = rgba.numel() * rgba.element_size()
         lib = _lib.load_library()
         probe_status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)  # (its own words: the render's were read above)
-        cs = torch.cuda.current_stream(dev).cuda_stream
+        cs = 0 if dry else torch.cuda.current_stream(dev).cuda_stream
 
         def timed(launch):
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
@@ -515,13 +603,17 @@ def main():
             torch.cuda.synchronize(dev)
             return vol_bytes / (min(e0.elapsed_time(e1) for e0, e1 in evs[1:]) * 1e-3) / 1e9
 
-        stream_gbs = timed(lambda: _lib.check(lib.gmpi_stream_probe_launch(rgba.data_ptr(), vol_bytes, probe_status.data_ptr(), cs), "gmpi_stream_probe_launch"))
-        range_check_gbs = timed(lambda: _lib.check(lib.gmpi_rgba_range_check_launch(rgba.data_ptr(), {"f32": 0, "bf16": 1}[dtype], rgba.numel(),
-                                                                                     probe_status.data_ptr(), cs), "gmpi_rgba_range_check_launch"))
+        if dry:
+            stream_gbs = range_check_gbs = 1.0
+        else:
+            stream_gbs = timed(lambda: _lib.check(lib.gmpi_stream_probe_launch(rgba.data_ptr(), vol_bytes, probe_status.data_ptr(), cs), "gmpi_stream_probe_launch"))
+            range_check_gbs = timed(lambda: _lib.check(lib.gmpi_rgba_range_check_launch(rgba.data_ptr(), {"f32": 0, "bf16": 1}[dtype], rgba.numel(),
+                                                                                         probe_status.data_ptr(), cs), "gmpi_rgba_range_check_launch"))
         line = {
             "metric": "Mpix*planes/s", "value": round(value, 1), "unit": "Mpix*planes/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "DRY RUN: no GPU, launches counted not executed -- no number of this line means anything" if dry else "synthetic",
             "config": {"workload": desc, "name": a.workload, "views_per_gpu": n_views, "H": S, "W": S, "planes": D,
                        "rgba_storage": dtype, "variant": a.variant, "strict_order": a.strict,
                        "outputs": "rgb+depth" + ("+transmittance" if want_T else ""), "parallelism": f"views sharded x{world}",
@@ -538,8 +630,10 @@ def main():
                          "footprint_bytes_per_launch": fbytes, "frac_footprint": round(fbytes / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "e2e_render_ms": round(e2e_ms, 3), "e2e_render_max_ms": round(e2e_max_ms, 3), "e2e_render_back_to_back_ms": round(e2e_b2b_ms, 3),
             "e2e_render_prefetched_poses_ms": round(e2e_pre_ms, 3), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
-            "pose_sweep": sweep,
+            "pose_sweep": sweep, "numa_pin": pinned,
         }
+        if dry:
+            line["dry_run"] = {"launches_on_rank0": dry_lib.launches, "gathered_shape": None if not use_dist else list(buf.shape)}
         if not a.no_parity:
             line["parity"] = parity_block(r, rgba, dhw, ray, eye, zd, vpm, want_T, S)
         if not a.no_cpu_baseline and world == 1:

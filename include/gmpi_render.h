@@ -67,7 +67,7 @@ enum {
     GMPI_VARIANT_GATHER = 1, /* one pixel per lane, taps straight from global memory (any shape/stride) */
     GMPI_VARIANT_LDS = 2,    /* pixel tiles, texel boxes staged through LDS with 16-byte row loads      */
     GMPI_VARIANT_WAVE = 3,   /* wave-private 32x8 pixel strips, whole RGBA texels (fp32 / fp16) in LDS  */
-    GMPI_VARIANT_DMA = 4,    /* pixel tiles, raw texel boxes moved HBM -> LDS by the LDS-DMA path (bf16 volumes)        */
+    GMPI_VARIANT_DMA = 4,    /* RETIRED (round 4): reserved, refused with GMPI_E_VARIANT; gmpi_query(7) == 0            */
     GMPI_VARIANT_BAND = 5    /* 256 x 8 (bf16) / 128 x 8 (fp32) pixel bands, LDS-DMA loader; needs the workspace               */
 };
 
@@ -253,7 +253,7 @@ int gmpi_stream_probe_launch(const void *buf, uint64_t bytes, uint32_t *sink, vo
 
 /* what: 0 ABI version, 1 sizeof(GmpiRenderParams), 2 target arch number (950), 3 LDS bytes the
  * LDS variant uses per workgroup, 4 pixel-tile width, 5 pixel-tile height, 6 whether
- * GMPI_VARIANT_WAVE is built in, 7 GMPI_VARIANT_DMA, 8 GMPI_VARIANT_BAND, 9 the number of 256 x 8 pixel bands from which
+ * GMPI_VARIANT_WAVE is built in, 7 GMPI_VARIANT_DMA (retired: 0), 8 GMPI_VARIANT_BAND, 9 the number of 256 x 8 pixel bands from which
  * GMPI_VARIANT_AUTO uses the band kernel on bf16 volumes, 10 the number of 128 x 8 pixel bands on fp32 volumes.  Unknown -> -1.                                        */
 int gmpi_query(int32_t what);
 

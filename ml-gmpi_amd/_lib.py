@@ -18,7 +18,7 @@ FLAG_ALIGN_CORNERS, FLAG_OUT_PM1, FLAG_CHECK_LAST_PLANE, FLAG_CHECK_RANGE, FLAG_
 STATUS_OUT_OF_LAST_PLANE, STATUS_RGBA_RANGE, STATUS_CAMERA_BEHIND_PLANE, STATUS_BAD_VIEW_INDEX = 1, 2, 4, 8
 STATUS_WORDS = 4
 VARIANT_AUTO, VARIANT_GATHER, VARIANT_LDS, VARIANT_WAVE, VARIANT_DMA, VARIANT_BAND = 0, 1, 2, 3, 4, 5
-VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS, "wave": VARIANT_WAVE, "dma": VARIANT_DMA, "band": VARIANT_BAND}
+VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS, "wave": VARIANT_WAVE, "band": VARIANT_BAND}  # (4 = the retired GMPI_VARIANT_DMA)
 
 EXPORTS = (
     "gmpi_mpi_render_launch",

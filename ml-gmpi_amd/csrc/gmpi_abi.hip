@@ -17,8 +17,6 @@ bool lds_variant_supports(const KParams& p, int dtype);                     // r
 int lds_variant_query(int what);                                            // render_lds.hip
 hipError_t launch_wave(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_wave.hip
 bool wave_variant_supports(const KParams& p, int dtype);                    // render_wave.hip
-hipError_t launch_dma(const KParams& p, int dtype, int tune, hipStream_t stream);   // render_dma.hip
-bool dma_variant_supports(const KParams& p, int dtype);                     // render_dma.hip
 hipError_t launch_band(const KParams& p, int dtype, int tune, hipStream_t stream);  // render_band.hip
 bool band_variant_supports(const KParams& p, int dtype);                    // render_band.hip
 uint64_t band_workspace_bytes(const KParams& p, int dtype);                 // render_band.hip
@@ -367,10 +365,8 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         if (!band_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
         return hip_rc(launch_band(p, params->rgba_dtype, tune, st));
     }
-    if (variant == GMPI_VARIANT_DMA) {
-        if (!dma_variant_supports(p, params->rgba_dtype)) return GMPI_E_VARIANT;
-        return hip_rc(launch_dma(p, params->rgba_dtype, tune, st));
-    }
+    // (GMPI_VARIANT_DMA -- round 3's LDS-DMA loader inside the 32 x 16 tile decomposition, the A/B that separated the loader from the
+    //  decomposition -- was retired in round 4: the band kernel is that loader's home.  The value stays reserved and is refused.)
     return GMPI_E_VARIANT;
 }
 
@@ -508,7 +504,7 @@ int gmpi_query(int32_t what) {
         case 2: return 950;
         case 3: case 4: case 5: return lds_variant_query(what);
         case 6: return 1;  // GMPI_VARIANT_WAVE is built in
-        case 7: return 1;  // GMPI_VARIANT_DMA is built in
+        case 7: return 0;  // GMPI_VARIANT_DMA: retired in round 4 (reserved value, refused with GMPI_E_VARIANT)
         case 8: return 1;  // GMPI_VARIANT_BAND is built in
         case 9: return static_cast<int>(kAutoBandMin);
         case 10: return static_cast<int>(kAutoBandMinF32);

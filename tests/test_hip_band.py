@@ -1,5 +1,5 @@
 """GPU parity tests of the round-3 kernels -- the band kernel (GMPI_VARIANT_BAND, render_band.hip: 256 x 8 pixel bands over bf16 volumes, 128 x 8
-over fp32 volumes), the LDS-DMA tile kernel (GMPI_VARIANT_DMA, render_dma.hip: bf16) -- and of GMPI_VARIANT_AUTO's two-kernel launch that shares
+over fp32 volumes) -- and of GMPI_VARIANT_AUTO's two-kernel launch that shares
 the views between the band kernel and the tile kernel on the device.  Same bars as test_hip_parity.py: strict-order mode == oracle bit for bit,
 default mode within 1e-5.  A bf16 volume is rendered by the oracle as its exact fp32 upcast (mpi_renderer.py:446)."""
 import ctypes
@@ -13,7 +13,7 @@ from test_hip_parity import TOL, _lib, _random_case, hip_render
 
 pytestmark = pytest.mark.gpu
 
-BF = ("band", "dma", "auto")
+BF = ("band", "auto")
 E_VARIANT = -6  # GMPI_E_VARIANT (include/gmpi_render.h)
 
 
@@ -65,7 +65,7 @@ def test_auto_shares_views_fp32():
     dict(seed=24, B=3, D=5, S=72, T=64),                    # image smaller than one band; rays leave the texture (zeros padding)
     dict(seed=25, B=2, D=16, S=320, T=256, extreme=True),   # tilted cameras at the truncation limit: boxes that do not fit -> gather path
 ])
-def test_band_and_dma_parity_bf16(cfg):
+def test_band_parity_bf16(cfg):
     _check(*_bf16_case(**cfg))
 
 

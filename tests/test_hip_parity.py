@@ -25,14 +25,11 @@ def _lib():
 
 
 def variants(bf16=False):
-    """Kernel variants built into the library (the band kernel takes fp32 and bf16 volumes and is refused -> AUTO for fp16);
-    bf16=True adds the LDS-DMA tile kernel, which only takes bf16 volumes."""
+    """Kernel variants built into the library (the band kernel takes fp32 and bf16 volumes and is refused -> AUTO for fp16)."""
     L = _lib()
     lib = L.load_library()
     v = ["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
     v += (["band"] if lib.gmpi_query(8) > 0 else []) + ["auto"]
-    if bf16:
-        v += ["dma"] if lib.gmpi_query(7) > 0 else []
     return v
 
 
@@ -56,7 +53,7 @@ def hip_render(rgba, dhw, ray_dir, eye, zdir, *, ac=True, variant="gather", stri
         except GmpiError as e:
             # shapes the LDS kernel cannot stage (texture width not a multiple of 4, unaligned strides) must be
             # refused when forced and handled by "auto" (which then picks the gather kernel)
-            if variant not in ("lds", "wave", "dma", "band") or "GMPI_E_VARIANT" not in str(e):
+            if variant not in ("lds", "wave", "band") or "GMPI_E_VARIANT" not in str(e):
                 raise
             mpi.variant = "auto"
             out = mpi.render_views(*args, **kw)
