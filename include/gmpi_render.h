@@ -49,7 +49,12 @@ enum {
                                             same pixels: the strip kernel's narrow boxes win on small frontal launches, the tile
                                             kernel's shared boxes on tilted ones (profiles/r03_pose_sweep.txt).  Results never
                                             depend on it; without it AUTO assumes a tilted camera.                              */
-    GMPI_FLAG_ALL = (1 << 6) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
+    GMPI_FLAG_HINT_TILTED = 1 << 6,      /* advisory (round 4), the other end: SOME view's camera axis is more than 0.53 rad off the MPI normal
+                                            (the 2-sigma corner of the FFHQ / MetFaces pose range).  The strip kernel's wave-private boxes
+                                            overflow there -- config 2 takes 0.25-0.77 ms instead of 0.16 -- while the tile kernel stays at
+                                            0.21 (profiles/r04_pose_distribution.txt): AUTO keeps such launches off the strip kernel.  Like
+                                            GMPI_FLAG_HINT_FRONTAL it never changes a result.                                            */
+    GMPI_FLAG_ALL = (1 << 7) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
 };
 
 /* bits of status[0] (OR-accumulated across launches until the caller clears the word) */

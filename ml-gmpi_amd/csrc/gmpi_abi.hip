@@ -324,8 +324,11 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         // more above 1024 strips) from 0.3 rad of yaw on (profiles/r03_pose_sweep.txt) -- the caller's GMPI_FLAG_HINT_FRONTAL decides;
         // without it: tilted.
         const bool frontal = (p.flags & GMPI_FLAG_HINT_FRONTAL) != 0;
+        // ... and beyond 0.53 rad of tilt (GMPI_FLAG_HINT_TILTED) the strip kernel's wave-private boxes overflow into half strips and the direct
+        // gather: config 2 takes 0.25-0.77 ms instead of 0.16 where the tile kernel stays at 0.21 (profiles/r04_pose_distribution.txt)
+        const bool tilted = (p.flags & GMPI_FLAG_HINT_TILTED) != 0;
         const bool small = strict ? (pixels <= (int64_t(1) << 19) && pixels > (int64_t(1) << 18))
-                         : params->rgba_dtype == GMPI_DTYPE_F32 ? (strips <= 512 || (strips > 1536 && strips <= 2048))
+                         : params->rgba_dtype == GMPI_DTYPE_F32 ? (strips <= 512 || (strips > 1536 && strips <= 2048 && !tilted))
                                                                 : (strips <= 512 || (strips <= 2048 && frontal));
         variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
         // Large launches over bf16 / fp32 volumes, when the caller lends a workspace: the band kernel (256 x 8 / 128 x 8 pixel bands, LDS-DMA;

@@ -101,6 +101,9 @@ int main(int argc, char** argv) {
             bool frontal = true;
             for (int n = 0; n < N; ++n) frontal = frontal && zd[n * 3 + 2] >= 0.98006658f;  // cos(0.2)
             if (frontal) p.flags |= GMPI_FLAG_HINT_FRONTAL;
+            bool tilted = false;
+            for (int n = 0; n < N; ++n) tilted = tilted || zd[n * 3 + 2] < 0.86280707f;  // cos(0.53)
+            if (tilted) p.flags |= GMPI_FLAG_HINT_TILTED;
         }
         CK(hipMemset(d_st, 0, 256)); CK(hipMemset(d_rgb, 0xff, npix * 12)); CK(hipMemset(d_dep, 0xff, npix * 4));
         int rc = launch(&p, nullptr);
