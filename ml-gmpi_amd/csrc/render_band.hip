@@ -504,6 +504,19 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
             constexpr int N = decltype(nb)::value;
             asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]) : "i"(N));
         };
+        // (the same for fp32 volumes: a batch = the 8 taps of two channels as four ds_read2_b32)
+        typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+        auto taps32_issue = [&](auto hb, uint32_t a_tap, uint32_t a_bot, u32x2_t (&v)[4]) {
+            constexpr int C0 = 2 * decltype(hb)::value;
+            asm volatile("ds_read2_b32 %0, %4 offset0:%6 offset1:%7\n\tds_read2_b32 %1, %5 offset0:%6 offset1:%7\n\t"
+                         "ds_read2_b32 %2, %4 offset0:%8 offset1:%9\n\tds_read2_b32 %3, %5 offset0:%8 offset1:%9"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                         : "v"(a_tap), "v"(a_bot), "i"(C0 * (kLineBytes / 4)), "i"(C0 * (kLineBytes / 4) + 1), "i"((C0 + 1) * (kLineBytes / 4)), "i"((C0 + 1) * (kLineBytes / 4) + 1));
+        };
+        auto taps32_land = [&](auto nb, u32x2_t (&v)[4]) {
+            constexpr int N = decltype(nb)::value;
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "i"(N));
+        };
         auto pixel = [&](int q, const float4& rf, const float2& rg) {
             Coords c;
             coords(q, rf, rg, c);
@@ -530,9 +543,10 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         uint32_t rhh_c, gp_c;
         uint32_t g_off = 0;  // this lane's loader offset: a vector register through the plane loop (round 3 re-read it from LDS behind every barrier)
 #ifdef GMPI_PROF  // (the phase stamps wait for lgkmcnt(0): they would serialise the pipeline they are meant to time)
-        constexpr bool piped = false;
+        constexpr bool piped = false, piped32 = false;
 #else
         constexpr bool piped = BF && !STRICT && PPT == 2;
+        constexpr bool piped32 = !BF && !STRICT && PPT == 1;
 #endif
         auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
             constexpr int U = decltype(ub)::value;
@@ -605,6 +619,43 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                     smp[2] = bilerp<false>(__uint_as_float(tb[0]), __uint_as_float(tb[1]), __uint_as_float(tb[2]), __uint_as_float(tb[3]), f);
                     smp[3] = bilerp<false>(__uint_as_float(tb[4]), __uint_as_float(tb[5]), __uint_as_float(tb[6]), __uint_as_float(tb[7]), f);
                     blend<false>(A[1], smp[0], smp[1], smp[2], smp[3], p1.s, dots[1]);
+                }
+            } else if constexpr (piped32) {
+                // fp32 volumes (one pixel per thread): c (2 x b128) | b0 (channels R G: 4 x ds_read2_b32) | b1 (B A)
+                if (abl_nocomp) {
+                    if (check_range) {
+                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                        check_fold(cq0), check_fold(cq1);
+                        check_tail();
+                    }
+                } else {
+                    u32x2_t va[4], vb[4];
+                    Coords p0;
+                    Footprint f;
+                    float smp[4];
+                    if (check_range) {
+                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                                     : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                    }
+                    coords(0, rf, rg, p0);
+                    const uint32_t a_bot = p0.a_tap + kRowBytes;
+                    taps32_issue(ic<0>{}, p0.a_tap, a_bot, va);                               // b0
+                    if (check_range) {
+                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(cq0), "+v"(cq1) : "i"(4));  // c has landed (b0 may still fly)
+                        check_fold(cq0), check_fold(cq1);
+                        check_tail();
+                    }
+                    taps32_issue(ic<1>{}, p0.a_tap, a_bot, vb);                               // b1
+                    taps32_land(ic<4>{}, va);
+                    f.nw = p0.nw, f.ne = p0.ne, f.sw = p0.sw, f.se = p0.se;
+                    smp[0] = bilerp<false>(__uint_as_float(va[0].x), __uint_as_float(va[0].y), __uint_as_float(va[1].x), __uint_as_float(va[1].y), f);
+                    smp[1] = bilerp<false>(__uint_as_float(va[2].x), __uint_as_float(va[2].y), __uint_as_float(va[3].x), __uint_as_float(va[3].y), f);
+                    asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));
+                    taps32_land(ic<0>{}, vb);
+                    smp[2] = bilerp<false>(__uint_as_float(vb[0].x), __uint_as_float(vb[0].y), __uint_as_float(vb[1].x), __uint_as_float(vb[1].y), f);
+                    smp[3] = bilerp<false>(__uint_as_float(vb[2].x), __uint_as_float(vb[2].y), __uint_as_float(vb[3].x), __uint_as_float(vb[3].y), f);
+                    blend<false>(A[0], smp[0], smp[1], smp[2], smp[3], p0.s, dots[0]);
                 }
             } else {
                 if (check_range) {

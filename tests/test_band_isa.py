@@ -48,5 +48,5 @@ def test_band_kernel_has_no_scratch_and_fits_two_workgroups_per_cu(tmp_path):
         body = asm[a:asm.index(".Lfunc_end", a)].split("\n")
         assert isa_pipe.check(body, name) == [], name
         piped += any(re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", l) for l in body)
-    assert piped == 4, piped   # the bf16 default-mode instances (align_corners x range check) are the pipelined ones
+    assert piped == 8, piped   # the default-mode instances (storage type x align_corners x range check) are the pipelined ones
     shutil.rmtree(tmp_path, ignore_errors=True)

@@ -7,13 +7,13 @@
 #   4) tools/prof_collect.py: summary.txt + hbm_traffic.json keyed by the kernel-source hash (bench.py quotes it only
 #      for matching sources).  Copy both into profiles/ afterwards.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-.}
-ARGS="--steps 12 --warmup 4 --no-cpu-baseline"
-timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+ARGS="--steps 12 --warmup 4 --no-cpu-baseline --no-parity --pose-draws 0"   # (the oracle comparison and the pose sweep are launches of their own: not in a counter average)
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-parity --pose-draws 0 > $OUT/bench_trace.log 2>&1
 tail -1 $OUT/bench_trace.log | cut -c1-300
 pmc() { # workload name counters...
   local wl=$1 name=$2; shift 2
