@@ -72,5 +72,5 @@ for i in range(n_cases):
             if not err <= tol:
                 print("DEFAULT-MODE MISMATCH", i, dict(H=H, W=W, Ht=Ht, Wt=Wt, D=D, B=B, preset=preset, ac=ac, dtype=str(dtype), mode=mode), variant, k, err)
                 sys.exit(1)
-print(f"fuzz ok: {n_cases} cases, {n_runs} (case, variant) pairs x 2 modes (gather / lds / wave / auto, + band on fp32 and bf16s) in {time.time() - t0:.0f} s; "
+print(f"fuzz ok: {n_cases} cases, {n_runs} (case, variant) pairs x 2 modes (gather / lds / wave / auto, + band on fp32 and bf16) in {time.time() - t0:.0f} s; "
       f"worst default-mode error {worst}")
