@@ -73,7 +73,7 @@ enum {
     GMPI_VARIANT_LDS = 2,    /* pixel tiles, texel boxes staged through LDS with 16-byte row loads      */
     GMPI_VARIANT_WAVE = 3,   /* wave-private 32x8 pixel strips, whole RGBA texels (fp32 / fp16) in LDS  */
     GMPI_VARIANT_DMA = 4,    /* RETIRED (round 4): reserved, refused with GMPI_E_VARIANT; gmpi_query(7) == 0            */
-    GMPI_VARIANT_BAND = 5    /* 256 x 8 (bf16) / 128 x 8 (fp32) pixel bands, LDS-DMA loader; needs the workspace               */
+    GMPI_VARIANT_BAND = 5    /* 256 x 8 (bf16, fp16) / 128 x 8 (fp32) pixel bands, LDS-DMA loader; needs the workspace         */
 };
 
 enum {

@@ -280,7 +280,7 @@ constexpr int64_t kAutoBandMinF32 = 1024;  // fp32: bands of 128 x 8 pixels (at 
 
 // does GMPI_VARIANT_AUTO consider the band kernel for this launch (given a workspace and the band kernel's alignment preconditions)?
 static bool auto_takes_band(const KParams& p, int dtype) {
-    if (dtype != GMPI_DTYPE_BF16 && dtype != GMPI_DTYPE_F32) return false;
+    if (dtype != GMPI_DTYPE_BF16 && dtype != GMPI_DTYPE_F32 && dtype != GMPI_DTYPE_F16) return false;
     // Views that share one MPI (views_per_mpi > 1: the video paths) stay with the tile kernel: it interleaves them per tile so that the
     // volume is read from HBM about once for the whole group (0.33x the algorithmic bytes on config 4) -- sharing the VIEWS out between two
     // kernels would read it once per kernel (measured on config 4: 1.14 ms against 0.545).
@@ -290,7 +290,7 @@ static bool auto_takes_band(const KParams& p, int dtype) {
     // (an image that fills less than 3/4 of its bands -- narrower than a band, a ragged last column -- wastes the idle lanes' issue slots:
     //  the tile kernel's 32 x 16 tiles fit such images better)
     if (static_cast<int64_t>(p.W) * 4 < cols * bw * 3 || static_cast<int64_t>(p.H) * 4 < rows * 8 * 3) return false;
-    return static_cast<int64_t>(p.N) * cols * rows >= (dtype == GMPI_DTYPE_BF16 ? kAutoBandMin : kAutoBandMinF32);
+    return static_cast<int64_t>(p.N) * cols * rows >= (dtype == GMPI_DTYPE_F32 ? kAutoBandMinF32 : kAutoBandMin);
 }
 
 static int hip_rc(hipError_t e) { return e == hipSuccess ? GMPI_OK : GMPI_E_LAUNCH - static_cast<int>(e); }
@@ -376,7 +376,6 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
 uint64_t gmpi_render_workspace_bytes(const GmpiRenderParams* params) {
     KParams p;
     if (to_kparams(params, p, true) != GMPI_OK || p.N == 0) return 0;
-    if (params->rgba_dtype == GMPI_DTYPE_F16) return 0;  // (the band kernel takes bf16 and fp32 volumes)
     if (params->variant == GMPI_VARIANT_BAND) return band_workspace_bytes(p, params->rgba_dtype);
     if (params->variant == GMPI_VARIANT_AUTO && auto_takes_band(p, params->rgba_dtype)) return band_workspace_bytes(p, params->rgba_dtype);
     return 0;

@@ -75,7 +75,7 @@ template <typename TexT> struct Geo {
     static constexpr int kOffBytes = kNT * 4;               // per-lane loader offsets (kept in LDS: a VGPR through the plane loop is dearer)
     static constexpr int kLdsBytes = kOffBytes + 2 * kBufBytes;
 };
-static_assert(Geo<bf16_t>::kLdsBytes * 2 <= 160 * 1024 && Geo<float>::kLdsBytes * 2 <= 160 * 1024, "2 workgroups per CU");
+static_assert(Geo<bf16_t>::kLdsBytes * 2 <= 160 * 1024 && Geo<f16_t>::kLdsBytes * 2 <= 160 * 1024 && Geo<float>::kLdsBytes * 2 <= 160 * 1024, "2 workgroups per CU");
 
 // One DMA instruction: lanes of `mask` move 16 bytes each from (descriptor base + voff + soff) to LDS byte M0 + 16 * lane.
 // (s_nop: an s_mov to M0 needs one wait state before an LDS-DMA reads it.)
@@ -248,7 +248,8 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
     constexpr int NSB = G::NSB, PPT = G::PPT, WPS = G::WPS, kSubLanes = G::kSubLanes;
     constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
     constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
-    constexpr bool BF = kES == 2;
+    constexpr bool BF = kES == 2;                              // 16-bit texels (bf16 or fp16): the two-pixel geometry, taps by ds_read_u16_d16_hi
+    constexpr bool F16 = std::is_same<TexT, f16_t>::value;     // fp16: the loaded half is the value's fp16 pattern -- converted inside the FMA (v_fma_mix_f32)
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::kLdsBytes];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
@@ -442,6 +443,17 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         };
 
         // ---- one pixel and plane, in three steps so that the taps of pixel q fly while the chain of pixel q + 1 issues ------------
+        // a tap register -> fp32.  bf16: the d16_hi load put the texel into the high half of a zeroed register, which IS its fp32 value.  fp16
+        // (round 4): the high half holds the fp16 pattern; the exact conversion folds into the bilinear FMAs (v_fma_mix_f32 with op_sel: no
+        // instruction of its own in default mode; strict-order mode converts first, one v_cvt_f32_f16 per tap).  fp32: the register is the value.
+        auto tapf = [&](uint32_t t) -> float {
+            if constexpr (F16) {
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                return static_cast<float>(__builtin_bit_cast(h2_t, t).y);
+            } else {
+                return __uint_as_float(t);
+            }
+        };
         struct Coords { float s, nw, ne, sw, se; uint32_t a_tap; };
         auto coords = [&](int q, const float4& rf, const float2& rg, Coords& c) {
             float ix, iy, fx, fy;
@@ -525,11 +537,11 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
             uint32_t t[8];
             float smp[4];
             taps(ic<0>{}, c.a_tap, t);
-            smp[0] = bilerp<STRICT>(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]), f);
-            smp[1] = bilerp<STRICT>(__uint_as_float(t[4]), __uint_as_float(t[5]), __uint_as_float(t[6]), __uint_as_float(t[7]), f);
+            smp[0] = bilerp<STRICT>(tapf(t[0]), tapf(t[1]), tapf(t[2]), tapf(t[3]), f);
+            smp[1] = bilerp<STRICT>(tapf(t[4]), tapf(t[5]), tapf(t[6]), tapf(t[7]), f);
             taps(ic<1>{}, c.a_tap, t);
-            smp[2] = bilerp<STRICT>(__uint_as_float(t[0]), __uint_as_float(t[1]), __uint_as_float(t[2]), __uint_as_float(t[3]), f);
-            smp[3] = bilerp<STRICT>(__uint_as_float(t[4]), __uint_as_float(t[5]), __uint_as_float(t[6]), __uint_as_float(t[7]), f);
+            smp[2] = bilerp<STRICT>(tapf(t[0]), tapf(t[1]), tapf(t[2]), tapf(t[3]), f);
+            smp[3] = bilerp<STRICT>(tapf(t[4]), tapf(t[5]), tapf(t[6]), tapf(t[7]), f);
             blend<STRICT>(A[q], smp[0], smp[1], smp[2], smp[3], c.s, dots[q]);
         };
 
@@ -600,24 +612,24 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                     asm volatile("" : "+v"(p1.s), "+v"(p1.nw), "+v"(p1.ne), "+v"(p1.sw), "+v"(p1.se), "+v"(p1.a_tap));
                     taps_land(ic<8>{}, ta);
                     f.nw = p0.nw, f.ne = p0.ne, f.sw = p0.sw, f.se = p0.se;
-                    smp[0] = bilerp<false>(__uint_as_float(ta[0]), __uint_as_float(ta[1]), __uint_as_float(ta[2]), __uint_as_float(ta[3]), f);
-                    smp[1] = bilerp<false>(__uint_as_float(ta[4]), __uint_as_float(ta[5]), __uint_as_float(ta[6]), __uint_as_float(ta[7]), f);
+                    smp[0] = bilerp<false>(tapf(ta[0]), tapf(ta[1]), tapf(ta[2]), tapf(ta[3]), f);
+                    smp[1] = bilerp<false>(tapf(ta[4]), tapf(ta[5]), tapf(ta[6]), tapf(ta[7]), f);
                     asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));
                     taps_issue(ic<0>{}, p1.a_tap, ta);                                        // b2
                     taps_land(ic<8>{}, tb);
-                    smp[2] = bilerp<false>(__uint_as_float(tb[0]), __uint_as_float(tb[1]), __uint_as_float(tb[2]), __uint_as_float(tb[3]), f);
-                    smp[3] = bilerp<false>(__uint_as_float(tb[4]), __uint_as_float(tb[5]), __uint_as_float(tb[6]), __uint_as_float(tb[7]), f);
+                    smp[2] = bilerp<false>(tapf(tb[0]), tapf(tb[1]), tapf(tb[2]), tapf(tb[3]), f);
+                    smp[3] = bilerp<false>(tapf(tb[4]), tapf(tb[5]), tapf(tb[6]), tapf(tb[7]), f);
                     blend<false>(A[0], smp[0], smp[1], smp[2], smp[3], p0.s, dots[0]);
                     asm volatile("" : "+v"(A[0].T), "+v"(A[0].r), "+v"(A[0].g), "+v"(A[0].b), "+v"(A[0].z));
                     taps_issue(ic<1>{}, p1.a_tap, tb);                                        // b3
                     taps_land(ic<8>{}, ta);
                     f.nw = p1.nw, f.ne = p1.ne, f.sw = p1.sw, f.se = p1.se;
-                    smp[0] = bilerp<false>(__uint_as_float(ta[0]), __uint_as_float(ta[1]), __uint_as_float(ta[2]), __uint_as_float(ta[3]), f);
-                    smp[1] = bilerp<false>(__uint_as_float(ta[4]), __uint_as_float(ta[5]), __uint_as_float(ta[6]), __uint_as_float(ta[7]), f);
+                    smp[0] = bilerp<false>(tapf(ta[0]), tapf(ta[1]), tapf(ta[2]), tapf(ta[3]), f);
+                    smp[1] = bilerp<false>(tapf(ta[4]), tapf(ta[5]), tapf(ta[6]), tapf(ta[7]), f);
                     asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));  // (pins the two samples in front of the last wait)
                     taps_land(ic<0>{}, tb);
-                    smp[2] = bilerp<false>(__uint_as_float(tb[0]), __uint_as_float(tb[1]), __uint_as_float(tb[2]), __uint_as_float(tb[3]), f);
-                    smp[3] = bilerp<false>(__uint_as_float(tb[4]), __uint_as_float(tb[5]), __uint_as_float(tb[6]), __uint_as_float(tb[7]), f);
+                    smp[2] = bilerp<false>(tapf(tb[0]), tapf(tb[1]), tapf(tb[2]), tapf(tb[3]), f);
+                    smp[3] = bilerp<false>(tapf(tb[4]), tapf(tb[5]), tapf(tb[6]), tapf(tb[7]), f);
                     blend<false>(A[1], smp[0], smp[1], smp[2], smp[3], p1.s, dots[1]);
                 }
             } else if constexpr (piped32) {
@@ -698,7 +710,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         // ---- the verdict of the range check.  -0.0 is a legal value whose pattern sits above that of 1.0: a maximum of exactly that pattern
         //      says nothing about the values below it, so such a band re-tests its texels one by one (cold: never for generator output) ----
         if (check_range) {
-            constexpr uint32_t kOne = BF ? 0x3f80u : 0x3f800000u, kNegZero = BF ? 0x8000u : 0x80000000u;
+            constexpr uint32_t kOne = F16 ? 0x3c00u : BF ? 0x3f80u : 0x3f800000u, kNegZero = BF ? 0x8000u : 0x80000000u;  // (the pattern of 1.0 / -0.0 in the storage type)
             const uint32_t mx = BF ? max(chk_acc & 0xffffu, chk_acc >> 16) : chk_acc;
 #ifdef GMPI_TUNE
             if (p.status != nullptr && mx > kOne) { atomicMax(p.status + 1, mx); atomicMax(p.status + 2, static_cast<uint32_t>(band_id)); atomicMax(p.status + 3, static_cast<uint32_t>(tid)); }
@@ -775,7 +787,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
 #endif
 }
 
-static int nsb_of(int dtype) { return dtype == 1 ? Geo<bf16_t>::NSB : Geo<float>::NSB; }
+static int nsb_of(int dtype) { return dtype != 0 ? Geo<bf16_t>::NSB : Geo<float>::NSB; }  // (bf16 and fp16 share the 16-bit geometry)
 static void band_grid(const KParams& p, int nsb, int& bands_x, int& bands_y, int& n_bands) {
     bands_x = (p.W + nsb * SBW - 1) / (nsb * SBW), bands_y = (p.H + SBH - 1) / SBH;
     n_bands = bands_x * bands_y * p.N;
@@ -831,8 +843,8 @@ uint32_t* band_gate_words(const KParams& p, int dtype) {
 }
 
 bool band_variant_supports(const KParams& p, int dtype) {
-    // bf16 and fp32 volumes.  fp16: a d16 load yields the half's bits, not an fp32 value (render_lds.hip converts while staging).
-    if (dtype != 0 && dtype != 1) return false;
+    // fp32, bf16 and (round 4) fp16 volumes: a d16_hi load of a bf16 texel IS its fp32 value; an fp16 texel is converted inside the bilinear FMAs.
+    if (dtype < 0 || dtype > 2) return false;
     const int nsb = band::nsb_of(dtype), bw = nsb * band::SBW;
     if (p.ws == nullptr || p.ws_bytes < band::ws_bytes(p, nsb) || reinterpret_cast<uintptr_t>(p.ws) % 256 != 0) return false;  // needs the caller's workspace
     if (static_cast<int64_t>(p.N) * p.D * ((p.W + bw - 1) / bw) * ((p.H + 7) / 8) > (int64_t(1) << 28)) return false;  // record indices stay in 32 bits
@@ -854,6 +866,7 @@ hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t strea
     (void)tune;
 #endif
     if (dtype == 1) return band::launch_t<bf16_t>(p, stream);
+    if (dtype == 2) return band::launch_t<f16_t>(p, stream);
     if (dtype == 0) return band::launch_t<float>(p, stream);
     return hipErrorInvalidValue;
 }

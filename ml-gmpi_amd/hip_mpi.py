@@ -138,7 +138,7 @@ class MPI(nn.Module):
 
     Extra constructor knobs (all optional; defaults reproduce the reference's behaviour):
       variant        "auto" | "gather" | "lds" | "wave" | "band"  -- kernel selection (GMPI_VARIANT_*); "auto" takes the band kernel
-                     for large launches over bf16 volumes and lets it share the views with the tile kernel (gmpi_render.h)
+                     for large launches (fp32 / bf16 / fp16 volumes) and lets it share the views with the tile kernel (gmpi_render.h)
       strict_order   one rounding per reference op also in the blend (bit-identical to the oracle)
       range_check    "touched" (alpha/rgba range asserted on the texels the render samples, free), "full" (extra
                      exhaustive pass = the reference's min/max over the whole volume, mpi.py:185-187 /

@@ -24,7 +24,7 @@ def test_band_kernel_has_no_scratch_and_fits_two_workgroups_per_cu(tmp_path):
     subprocess.run([HIPCC, *flags, "-save-temps", "-c", src, "-o", "render_band.o"], cwd=tmp_path, check=True, capture_output=True, timeout=900)
     asm = open(os.path.join(tmp_path, "render_band-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     names = sorted(set(re.findall(r"^(_ZN4gmpi4band18render_band_kernel\w+):", asm, flags=re.M)))
-    assert len(names) == 16, names   # {bf16, fp32} x align_corners x strict order x range check
+    assert len(names) == 24, names   # {bf16, fp16, fp32} x align_corners x strict order x range check
     for name in names:
         a = asm.index(name + ":")
         body = asm[a:asm.index(".Lfunc_end", a)]
@@ -48,5 +48,5 @@ def test_band_kernel_has_no_scratch_and_fits_two_workgroups_per_cu(tmp_path):
         body = asm[a:asm.index(".Lfunc_end", a)].split("\n")
         assert isa_pipe.check(body, name) == [], name
         piped += any(re.search(r"s_waitcnt lgkmcnt\([1-9]\d*\)", l) for l in body)
-    assert piped == 8, piped   # the default-mode instances (storage type x align_corners x range check) are the pipelined ones
+    assert piped == 12, piped   # the default-mode instances (storage type x align_corners x range check) are the pipelined ones
     shutil.rmtree(tmp_path, ignore_errors=True)

@@ -69,6 +69,33 @@ def test_band_parity_bf16(cfg):
     _check(*_bf16_case(**cfg))
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(seed=71, B=2, D=16, S=256),                        # one band column
+    dict(seed=72, B=1, D=9, S=512),                         # two band columns
+    dict(seed=73, B=2, D=7, S=200, T=208),                  # ragged image, texture != image
+    dict(seed=74, B=2, D=8, S=320, T=256, extreme=True),    # tilted cameras: boxes that do not fit, rays that leave the texture
+])
+def test_band_parity_fp16(cfg):
+    """fp16 volumes (round 4): the d16_hi load yields the texel's fp16 pattern, converted inside the bilinear FMAs (v_fma_mix_f32) -- strict mode
+    bit-identical to the oracle run on the exact fp32 upcast of the stored values, default mode within the bar."""
+    rgba, dhw, ray, eye, zd = _random_case(**cfg)
+    _check(rgba.to(torch.float16), dhw, ray, eye, zd, variants=("band", "auto"))
+
+
+def test_band_range_check_fp16():
+    rgba, dhw, ray, eye, zd = _random_case(seed=75, B=2, D=6, S=256)
+    vol = rgba.to(torch.float16)
+    for value in (1.25, -0.5, float("nan"), float("inf")):
+        bad = vol.clone()
+        bad[1, 3, 2, 100:140, 90:150] = value
+        with pytest.raises(AssertionError):
+            hip_render(bad, dhw, ray, eye, zd, variant="band")
+    nz = vol.clone()
+    nz[:, :, :, 60:200, 60:200][vol[:, :, :, 60:200, 60:200] < 0.25] = -0.0   # negative zeros are legal
+    out = hip_render(nz, dhw, ray, eye, zd, variant="band", strict=True)
+    assert int(out["status"][0]) == 0 and np.array_equal(out["color"], oracle.render(nz.float(), dhw, ray, eye, zd)["color"])
+
+
 def test_auto_shares_views_between_band_and_tile_kernels():
     """A launch large enough for AUTO's band path (>= gmpi_query(9) bands) whose views are partly frontal, partly tilted beyond what the band
     kernel stages: every view must come out once, bit-exact, whichever kernel the device-side gate hands it to."""
@@ -196,7 +223,7 @@ def test_workspace_contract():
     assert need > 0
     assert lib.gmpi_render_workspace_bytes(ctypes.byref(params("auto", d[0]))) == 0   # 64 bands: below AUTO's band threshold
     assert lib.gmpi_render_workspace_bytes(ctypes.byref(params("band", d[0].float()))) > need  # fp32: twice the bands (128 pixels wide)
-    assert lib.gmpi_render_workspace_bytes(ctypes.byref(params("band", d[0].to(torch.float16)))) == 0  # fp16 volume: no kernel wants scratch
+    assert lib.gmpi_render_workspace_bytes(ctypes.byref(params("band", d[0].to(torch.float16)))) == need  # fp16 volume: the bf16 geometry (round 4)
     assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == E_VARIANT            # no workspace
     ws = torch.empty(need + 256, dtype=torch.uint8, device=dev)
     p.workspace, p.workspace_bytes = ws.data_ptr(), need - 1
@@ -208,9 +235,13 @@ def test_workspace_contract():
     torch.cuda.synchronize()
     orc = oracle.render(rgba.float(), dhw, ray, eye, zd)
     assert np.array_equal(color.cpu().numpy(), orc["color"]) and int(status[0]) == 0
-    ph = params("band", d[0].to(torch.float16))
+    vol16 = d[0].to(torch.float16)
+    ph = params("band", vol16)
     ph.workspace, ph.workspace_bytes = ws.data_ptr(), need
-    assert lib.gmpi_mpi_render_launch(ctypes.byref(ph), None) == E_VARIANT           # fp16 volumes are not the band kernel's
+    assert lib.gmpi_mpi_render_launch(ctypes.byref(ph), None) == 0                   # fp16 volumes: the band kernel's since round 4
+    torch.cuda.synchronize()
+    orc16 = oracle.render(vol16.float(), dhw, ray, eye, zd)
+    assert np.array_equal(color.cpu().numpy(), orc16["color"]) and int(status[0]) == 0
 
 
 def test_frontal_hint_changes_no_result():

@@ -25,7 +25,7 @@ def _lib():
 
 
 def variants(bf16=False):
-    """Kernel variants built into the library (the band kernel takes fp32 and bf16 volumes and is refused -> AUTO for fp16)."""
+    """Kernel variants built into the library (the band kernel takes fp32, bf16 and -- since round 4 -- fp16 volumes)."""
     L = _lib()
     lib = L.load_library()
     v = ["gather"] + (["lds"] if lib.gmpi_query(3) > 0 else []) + (["wave"] if lib.gmpi_query(6) > 0 else [])
