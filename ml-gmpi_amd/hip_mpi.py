@@ -15,6 +15,7 @@ import collections
 import contextlib
 import ctypes
 import sys
+import threading
 from typing import List, Optional, Sequence, Union
 
 import numpy as np
@@ -26,16 +27,45 @@ from . import _lib
 _DTYPES = {torch.float32: _lib.DTYPE_F32, torch.bfloat16: _lib.DTYPE_BF16, torch.float16: _lib.DTYPE_F16}
 
 
+# Per-(device, stream) state of this module -- the scratch lent to the C ABI, the status words -- lives in small LRU caches (a program that
+# creates many streams would otherwise leak one workspace, ~12 MB at config 3, per stream), and every launch on a stream holds that
+# stream's lock from the marshalling of its parameters to the launch: two host threads on one stream would otherwise race on the workspace
+# (the C header forbids concurrent calls that share one) and on the status words.
+_MAX_STREAMS = 8
+_CACHE_LOCK = threading.Lock()
+_STREAM_LOCKS = {}
+
+
+def _lru_get(cache, key, make):
+    with _CACHE_LOCK:
+        hit = cache.pop(key, None)
+        if hit is None:
+            hit = make()
+            while len(cache) >= _MAX_STREAMS:
+                cache.pop(next(iter(cache)))   # the least recently used entry (dicts keep insertion order)
+        cache[key] = hit
+        return hit
+
+
+def _stream_key(dev: torch.device, stream: int):
+    return (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
+
+
+def _stream_lock(dev: torch.device, stream: int) -> threading.RLock:
+    return _lru_get(_STREAM_LOCKS, _stream_key(dev, stream), threading.RLock)
+
+
 # Scratch lent to the C ABI (GmpiRenderParams.workspace), one per device and stream: a call in flight on another stream must not share it.
 _WORKSPACES = {}
 
 
 def _workspace(dev: torch.device, stream: int, need: int) -> torch.Tensor:
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
-    ws = _WORKSPACES.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)  # (the caching allocator hands out 512-byte aligned blocks)
-        _WORKSPACES[key] = ws
+    key = _stream_key(dev, stream)
+    ws = _lru_get(_WORKSPACES, key, lambda: torch.empty(need, dtype=torch.uint8, device=dev))  # (the caching allocator hands out 512-byte aligned blocks)
+    if ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        with _CACHE_LOCK:
+            _WORKSPACES[key] = ws
     return ws
 
 
@@ -46,11 +76,7 @@ _STATUS = {}
 
 
 def _own_status(dev: torch.device, stream: int) -> torch.Tensor:
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
-    st = _STATUS.get(key)
-    if st is None:
-        st = _STATUS[key] = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
-    return st
+    return _lru_get(_STATUS, _stream_key(dev, stream), lambda: torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev))
 
 
 # Lagged status (defer_status="lag": the default of `MPIRenderer.render`).  The assertions of a render are status bits the kernel ORs into a
@@ -95,10 +121,16 @@ class _StatusRing:
 
 
 def _ring(dev: torch.device, stream: int) -> _StatusRing:
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream)
-    ring = _RINGS.get(key)
-    if ring is None:
-        ring = _RINGS[key] = _StatusRing(dev)
+    key = _stream_key(dev, stream)
+    with _CACHE_LOCK:
+        ring = _RINGS.get(key)
+        if ring is None:
+            if len(_RINGS) >= _MAX_STREAMS:   # (a ring with pending slots is never dropped: the oldest drained one goes)
+                for k, old in list(_RINGS.items()):
+                    if not old.pending:
+                        del _RINGS[k]
+                        break
+            ring = _RINGS[key] = _StatusRing(dev)
     return ring
 
 
@@ -281,75 +313,84 @@ class MPI(nn.Module):
             T = out.get("T")
             if T is None:
                 T = torch.empty((N, 1, H, W), dtype=torch.float32, device=dev)
-        lag = defer_status == "lag" and status is None and on_device and not _in_autograd_fn
-        if defer_status == "lag" and not lag:
-            defer_status = False   # (a caller-owned status tensor, the autograd bridge, the recorder library: read back at once)
-        ring = slot = None
-        if lag:
-            ring = _ring(dev, torch.cuda.current_stream(dev).cuda_stream)
-            slot = ring.acquire()   # (raises here what an earlier call asserted)
-            status = ring.dev_words[slot]
-        elif status is None:
-            if on_device and not defer_status and not _in_autograd_fn:
-                status = _own_status(dev, torch.cuda.current_stream(dev).cuda_stream)
-            else:
-                status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        # (from here to the launch -- status slot, workspace, parameter struct -- under the stream's lock: see _stream_lock)
+        lock = _stream_lock(dev, torch.cuda.current_stream(dev).cuda_stream) if on_device else contextlib.nullcontext()
+        with lock:
+            lag = defer_status == "lag" and status is None and on_device and not _in_autograd_fn
+            if defer_status == "lag" and not lag:
+                defer_status = False   # (a caller-owned status tensor, the autograd bridge, the recorder library: read back at once)
+            ring = slot = None
+            if lag:
+                ring = _ring(dev, torch.cuda.current_stream(dev).cuda_stream)
+                slot = ring.acquire()   # (raises here what an earlier call asserted)
+                status = ring.dev_words[slot]
+            elif status is None:
+                if on_device and not defer_status and not _in_autograd_fn:
+                    status = _own_status(dev, torch.cuda.current_stream(dev).cuda_stream)
+                else:
+                    status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
 
-        flags = 0
-        if self._align_corners:
-            flags |= _lib.FLAG_ALIGN_CORNERS
-        if out_pm1:
-            flags |= _lib.FLAG_OUT_PM1
-        if check_last_plane:
-            flags |= _lib.FLAG_CHECK_LAST_PLANE
-        if self.range_check != "off":
-            flags |= _lib.FLAG_CHECK_RANGE
-        if self.strict_order:
-            flags |= _lib.FLAG_STRICT_ORDER
-        if frontal_hint:
-            flags |= _lib.FLAG_HINT_FRONTAL
-        if tilted_hint:
-            flags |= _lib.FLAG_HINT_TILTED
+            flags = 0
+            if self._align_corners:
+                flags |= _lib.FLAG_ALIGN_CORNERS
+            if out_pm1:
+                flags |= _lib.FLAG_OUT_PM1
+            if check_last_plane:
+                flags |= _lib.FLAG_CHECK_LAST_PLANE
+            if self.range_check != "off":
+                flags |= _lib.FLAG_CHECK_RANGE
+            if self.strict_order:
+                flags |= _lib.FLAG_STRICT_ORDER
+            if frontal_hint:
+                flags |= _lib.FLAG_HINT_FRONTAL
+            if tilted_hint:
+                flags |= _lib.FLAG_HINT_TILTED
 
-        p = _lib.GmpiRenderParams()
-        p.struct_size = ctypes.sizeof(_lib.GmpiRenderParams)
-        p.flags = flags
-        p.variant = _lib.VARIANTS[self.variant]
-        p.rgba_dtype = _DTYPES[rgba.dtype]
-        p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W = N, M, D, Ht, Wt, H, W
-        p.views_per_mpi = max(uniform, 1)
-        p.rgba = rgba.data_ptr()
-        for i, s in enumerate(rgba.stride()):
-            p.rgba_stride[i] = s
-        p.view_to_mpi = view_to_mpi.data_ptr() if view_to_mpi is not None else None
-        p.dhw, p.ray_dir, p.eye_pos, p.z_dir = dhw.data_ptr(), ray_dir.data_ptr(), eye_pos.data_ptr(), z_dir.data_ptr()
-        p.rgb_out, p.depth_out = color.data_ptr(), depth.data_ptr()
-        p.transmittance_out = T.data_ptr() if T is not None else None
-        p.status = status.data_ptr()
-        stream = torch.cuda.current_stream(dev).cuda_stream if on_device else 0
-        if on_device:  # scratch for the kernels that want some (the band kernel's geometry table): 0 bytes for most launches
-            need = int(lib.gmpi_render_workspace_bytes(ctypes.byref(p)))
-            if need:
-                ws = _workspace(dev, stream, need)
-                p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
-        with _on_device(dev if on_device else None):
-            if self.range_check == "full":
-                vol = rgba if rgba.is_contiguous() else rgba.contiguous()
-                _lib.check(lib.gmpi_rgba_range_check_launch(vol.data_ptr(), p.rgba_dtype, vol.numel(),
-                                                            status.data_ptr(), stream), "gmpi_rgba_range_check_launch")
-            _lib.check(lib.gmpi_mpi_render_launch(ctypes.byref(p), stream), "gmpi_mpi_render_launch")
-        res = dict(color=color, depth=depth, T=T, status=status)
-        if _in_autograd_fn:  # what the backward needs to rebuild the launch
-            res["_bwd"] = (p, (rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi))
-        if lag:
-            ring.host_words[slot].copy_(status, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(dev))
-            ring.pending.append((slot, ev, self, p, (rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi), c2w_mat, sphere_c))
-        elif not defer_status:
-            self.raise_on_status(status, params=p, keep=(rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi),
-                                 c2w_mat=c2w_mat, sphere_c=sphere_c)
-        return res
+            p = _lib.GmpiRenderParams()
+            p.struct_size = ctypes.sizeof(_lib.GmpiRenderParams)
+            p.flags = flags
+            p.variant = _lib.VARIANTS[self.variant]
+            p.rgba_dtype = _DTYPES[rgba.dtype]
+            p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W = N, M, D, Ht, Wt, H, W
+            p.views_per_mpi = max(uniform, 1)
+            p.rgba = rgba.data_ptr()
+            for i, s in enumerate(rgba.stride()):
+                p.rgba_stride[i] = s
+            p.view_to_mpi = view_to_mpi.data_ptr() if view_to_mpi is not None else None
+            p.dhw, p.ray_dir, p.eye_pos, p.z_dir = dhw.data_ptr(), ray_dir.data_ptr(), eye_pos.data_ptr(), z_dir.data_ptr()
+            p.rgb_out, p.depth_out = color.data_ptr(), depth.data_ptr()
+            p.transmittance_out = T.data_ptr() if T is not None else None
+            p.status = status.data_ptr()
+            stream = torch.cuda.current_stream(dev).cuda_stream if on_device else 0
+            if on_device:  # scratch for the kernels that want some (the band kernel's geometry table): 0 bytes for most launches
+                need = int(lib.gmpi_render_workspace_bytes(ctypes.byref(p)))
+                if need:
+                    ws = _workspace(dev, stream, need)
+                    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
+            with _on_device(dev if on_device else None):
+                if self.range_check == "full":
+                    vol = rgba if rgba.is_contiguous() else rgba.contiguous()
+                    _lib.check(lib.gmpi_rgba_range_check_launch(vol.data_ptr(), p.rgba_dtype, vol.numel(),
+                                                                status.data_ptr(), stream), "gmpi_rgba_range_check_launch")
+                _lib.check(lib.gmpi_mpi_render_launch(ctypes.byref(p), stream), "gmpi_mpi_render_launch")
+            res = dict(color=color, depth=depth, T=T, status=status)
+            if _in_autograd_fn:  # what the backward needs to rebuild the launch
+                res["_bwd"] = (p, (rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi))
+            if lag:
+                ring.host_words[slot].copy_(status, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                ring.pending.append((slot, ev, self, p, (rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi), c2w_mat, sphere_c))
+            elif not defer_status:
+                try:
+                    self.raise_on_status(status, params=p, keep=(rgba, dhw, ray_dir, eye_pos, z_dir, view_to_mpi),
+                                         c2w_mat=c2w_mat, sphere_c=sphere_c)
+                except BaseException:
+                    # (also a KeyboardInterrupt between the launch and the read-back: the shared words must not keep bits for the next call)
+                    if status.is_cuda:
+                        status.zero_()
+                    raise
+            return res
 
     # -- status word -> the reference's assertion behaviour ------------------------------------------------------
     def raise_on_status(self, status: torch.Tensor, params=None, keep=None, c2w_mat=None, sphere_c=None):

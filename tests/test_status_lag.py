@@ -63,3 +63,43 @@ def test_ring_wraps_and_sync_mode_raises_at_once():
     bad[0, 1, 3] = -0.25
     with torch.no_grad(), pytest.raises(AssertionError, match="alpha to be within"):
         r2.render(bad, S2, S2)
+
+
+def test_per_stream_state_is_bounded_and_thread_safe():
+    """The workspace / status caches are LRU-bounded (a program that creates many streams does not leak a workspace per stream), and two host
+    threads that render on ONE stream are serialised by that stream's lock (the C header forbids concurrent calls that share a workspace)."""
+    import threading
+    from ml_gmpi_amd import hip_mpi
+    m, r, rgba, S = _setup(D=4, S=512, B=5)            # 5 views of 512^2: AUTO's band path -> a workspace per stream
+    rgba = rgba.to(torch.bfloat16)
+    with torch.no_grad():
+        ref = r.render(rgba, S, S, given_yaws=torch.zeros(5, 1), given_pitches=torch.zeros(5, 1))[0].clone()
+        for _ in range(12):                            # more streams than cache entries
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                out = r.render(rgba, S, S, given_yaws=torch.zeros(5, 1), given_pitches=torch.zeros(5, 1))[0]
+            st.synchronize()
+            assert torch.equal(out, ref)
+    m.flush_status()
+    assert len(hip_mpi._WORKSPACES) <= hip_mpi._MAX_STREAMS and len(hip_mpi._RINGS) <= hip_mpi._MAX_STREAMS
+    errors = []
+
+    def worker():
+        try:
+            r2 = m.make_renderer("FFHQ", n_planes=4, device=torch.device("cuda:0"), on_out_of_plane="raise")
+            with torch.no_grad():
+                for _ in range(20):
+                    o = r2.render(rgba, S, S, given_yaws=torch.zeros(5, 1), given_pitches=torch.zeros(5, 1))[0]
+                    torch.cuda.synchronize()
+                    if not torch.equal(o, ref):
+                        errors.append("mismatch")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker) for _ in range(3)]   # all on the default stream of cuda:0
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    m.flush_status()
+    assert not errors, errors[:3]
