@@ -91,6 +91,46 @@ def render_views_sharded(render_fn: Callable[[List[int]], torch.Tensor], n_views
     return gather_frames(local, indices, n_views, group=group)
 
 
+def dump_frames(save_dir: str, task: str, start_index: int, img8, angles, depth=None, n_view_per_z: int = 1) -> List[str]:
+    """Writes rendered frames in the on-disk layout of the reference's dataset dumps (prepare_fake_data.py:184-190, 226-258):
+
+        <save_dir>/<task>/rgb/<idx:06d>.png      uint8 RGB            (n_view_per_z == 1)
+        <save_dir>/<task>/angle/<idx:06d>.npy    [2] = (pitch, yaw)
+        <save_dir>/<task>/depth/<idx:06d>.npy    [H, W] float32       (only with `depth`)
+        ... and `<idx:06d>_<j>.*` for view j of seed idx when n_view_per_z > 1 (the "consistency" task).
+
+    img8 [N,H,W,3] uint8 (host or device; e.g. `frames_to_uint8` / `ViewBatchDriver.render_path(..., to_uint8=True)["img8"]`), angles [N,2],
+    depth [N,H,W] or [N,1,H,W] float32.  N = seeds x n_view_per_z, seed-major; the first seed gets index `start_index`.  Returns the PNG paths."""
+    import os
+
+    import numpy as np
+    from PIL import Image
+
+    def host(t):
+        return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    img8, angles = host(img8), host(angles)
+    assert img8.dtype == np.uint8 and img8.ndim == 4 and img8.shape[-1] == 3, (img8.dtype, img8.shape)
+    assert img8.shape[0] % n_view_per_z == 0 and angles.shape[0] == img8.shape[0]
+    if depth is not None:
+        depth = host(depth).astype(np.float32).reshape(img8.shape[0], img8.shape[1], img8.shape[2])
+    dirs = {k: os.path.join(save_dir, task, k) for k in ("rgb", "depth", "angle")}
+    for d in dirs.values():
+        os.makedirs(d, exist_ok=True)
+    paths = []
+    for n in range(img8.shape[0]):
+        seed, j = divmod(n, n_view_per_z)
+        name = f"{start_index + seed:06d}" if n_view_per_z == 1 else f"{start_index + seed:06d}_{j}"
+        Image.fromarray(img8[n]).save(os.path.join(dirs["rgb"], name + ".png"))
+        with open(os.path.join(dirs["angle"], name + ".npy"), "wb") as f:
+            np.save(f, angles[n])
+        if depth is not None:
+            with open(os.path.join(dirs["depth"], name + ".npy"), "wb") as f:
+                np.save(f, depth[n])
+        paths.append(os.path.join(dirs["rgb"], name + ".png"))
+    return paths
+
+
 class ViewBatchDriver:
     """Renders a camera path / a batch of seeds with an `MPIRenderer`, `batch` views per launch, device-resident."""
 

@@ -90,3 +90,22 @@ def test_gather_single_process_path():
     local = _frames_for([0, 2])
     out = gather_frames(local, [0, 1], 2)
     assert torch.equal(out, local)
+
+
+def test_dump_frames_writes_the_reference_layout(tmp_path):
+    """prepare_fake_data.py:184-190, 226-258: <save_dir>/<task>/{rgb,angle,depth}/<idx:06d>[_<j>].{png,npy}."""
+    import numpy as np
+    from PIL import Image
+    import ml_gmpi_amd
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(4, 8, 8, 3), dtype=np.uint8)
+    ang = rng.random((4, 2)).astype(np.float32)
+    dep = rng.random((4, 1, 8, 8)).astype(np.float32)
+    paths = ml_gmpi_amd.dump_frames(str(tmp_path), "fid", 10, img, ang, depth=dep)
+    assert [os.path.basename(p) for p in paths] == ["000010.png", "000011.png", "000012.png", "000013.png"]
+    assert np.array_equal(np.asarray(Image.open(paths[2])), img[2])
+    assert np.array_equal(np.load(tmp_path / "fid" / "angle" / "000012.npy"), ang[2])
+    assert np.array_equal(np.load(tmp_path / "fid" / "depth" / "000013.npy"), dep[3, 0])
+    paths = ml_gmpi_amd.dump_frames(str(tmp_path), "consistency", 0, torch.from_numpy(img), torch.from_numpy(ang), n_view_per_z=2)
+    assert [os.path.basename(p) for p in paths] == ["000000_0.png", "000000_1.png", "000001_0.png", "000001_1.png"]
+    assert not (tmp_path / "consistency" / "depth" / "000000_0.npy").exists()
