@@ -27,6 +27,54 @@ def test_gaussian_kernel_matches_oracle_and_sums_to_one():
     assert abs(float(k.sum()) - 1.0) <= 1e-6 and np.array_equal(k, k[::-1])
 
 
+def _scipy_blur(depth, ksize=9):
+    """The blur step pinned against a THIRD-PARTY implementation (torchvision is absent from this image, so the fixture's blur
+    is a stand-in that restates torchvision's `gaussian_blur`, oracle/make_golden.py `_torchvision_stand_in`): torchvision's
+    operator -- 1-D weights exp(-x^2 / (2 sigma^2)) on the integers -(k-1)/2 .. (k-1)/2, normalised to 1, applied along both
+    axes with `reflect` padding (no repeat of the edge sample) -- is what scipy.ndimage.gaussian_filter1d computes with
+    radius (k-1)/2 and mode="mirror" (scipy's name for the same boundary); scipy builds its own weights and walks its own
+    boundary code, in float64."""
+    import scipy.ndimage as ndi
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8   # light_renderer.py:50
+    d = np.asarray(depth, dtype=np.float64)
+    for axis in (-2, -1):
+        d = ndi.gaussian_filter1d(d, sigma, axis=axis, mode="mirror", radius=(ksize - 1) // 2)
+    return d
+
+
+def test_blur_operators_match_scipy():
+    """oracle blur weights / the product's reflect-padded blur matrices / the fixture generator's stand-in, all against scipy."""
+    from ml_gmpi_amd.light import gaussian_kernel1d, _blur_matrix, _blur_torch
+    rng = np.random.default_rng(5)
+    for H, W in ((32, 32), (9, 17), (5, 40)):   # (5: the image is narrower than the kernel's reach + 1 -- reflect needs pad < size: 4 < 5)
+        depth = rng.uniform(0.9, 1.2, size=(2, 1, H, W)).astype(np.float32)
+        want = _scipy_blur(depth)
+        k1 = gaussian_kernel1d(9, 0.3 * ((9 - 1) * 0.5 - 1) + 0.8)
+        got = _blur_torch(torch.from_numpy(depth), _blur_matrix(H, k1, torch.device("cpu")), _blur_matrix(W, k1, torch.device("cpu"))).numpy()
+        assert np.abs(got - want).max() <= 1.5e-6, (H, W, np.abs(got - want).max())   # (fp32 sums of 81 terms near 1.0)
+        # the stand-in that made tests/golden/light_render.npz
+        import importlib.util, os
+        spec = importlib.util.spec_from_file_location("make_golden_standin", os.path.join(os.path.dirname(oracle.__file__), "make_golden.py"))
+        src = open(spec.origin).read()
+        ns = {"torch": torch}
+        a = src.index("def _torchvision_stand_in():")
+        exec(src[a:src.index("def run_light_render():")], ns)
+        blur = ns["_torchvision_stand_in"]().transforms.GaussianBlur(kernel_size=(9, 9), sigma=(0.3 * ((9 - 1) * 0.5 - 1) + 0.8,) * 2)
+        ref = blur(torch.from_numpy(depth)).numpy()
+        assert np.abs(ref - want).max() <= 1.5e-6, (H, W, np.abs(ref - want).max())
+
+
+@pytest.mark.gpu
+def test_hip_blur_kernel_matches_scipy():
+    import ml_gmpi_amd
+    L = ml_gmpi_amd.LightRenderer(sphere_center_z=1.0, sphere_r=1.0)
+    rng = np.random.default_rng(6)
+    for H, W in ((32, 32), (9, 17), (5, 40), (256, 256)):
+        depth = rng.uniform(0.9, 1.2, size=(3, 1, H, W)).astype(np.float32)
+        got = L.blurrer_func(torch.from_numpy(depth).to("cuda:0")).cpu().numpy()
+        assert np.abs(got - _scipy_blur(depth)).max() <= 1.5e-6, (H, W)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,kw,steps", [("kd", dict(ka_max=0.6, kd_max=0.9, n_grow_iters=4), 3),
                                            ("ambient", dict(ka_max=1.0, kd_max=0.0, n_grow_iters=2), 2)])
