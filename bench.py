@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the MPI render hot path on MI355X (one JSON line on rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg3_f32|cfg4|cfg5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg3_f32|cfg4|cfg5|video]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -23,6 +23,20 @@ launch call on the launch stream; wall time per step).  Algorithmic bytes (SURVE
     N*D*4*Ht*Wt*s_in  +  N*H*W*12 (ray_dir)  +  N*H*W*4*(3+1[+1]) (outputs)
 cpu_baseline = the CPU oracle (oracle/mpi_oracle.c, OpenMP build, kind "port") timed on this box's
 host cores on a bounded sample of the same workload -- a reported baseline, not the target.
+
+Further blocks of the line, all OUTSIDE the K timed steps (rank 0, N = 1 unless noted):
+    parity      the timed launch itself (same tensors, same variant) rendered once in strict-order mode and once in default mode and
+                compared with the CPU oracle on three 64x64 ray windows per view: strict_bit_exact, max_abs_err_{color,depth,T}, bar 1e-5.
+                A failure makes the process exit non-zero (--no-parity skips it: the PMC passes of tools/prof.sh).
+    pose_sweep  --pose-draws (default 32) seeded draws of the preset's pose distribution through the same launch: mean / p50 / p90 /
+                worst ms per step and the share of views the band kernel handed to the tile kernel (read from the workspace header).
+                The headline `value` stays on the draw SURVEY.md 8(d) prescribes (torch.manual_seed(3)).
+    e2e_render  `MPIRenderer.render()` through the product's host path (pose draw, ray kernel, launch, lagged status): mean and max over
+                fresh draws, and back to back without a synchronisation in between (what a loop of calls pays).
+    --workload video  the reference's render_video.py loop shape (one 512^2 view per call over a yaw sweep, `.cpu()` per view) through the
+                installed drop-in, next to ViewBatchDriver.render_path on the same path: views/s of both (metric "views/s").
+    --dry-run   no GPU: the rank / rendezvous / gather / JSON logic with a launch-counting stand-in library on the gloo backend
+                (tests/test_bench_ranks_gloo.py runs it at world size 8); --numa-pin binds a rank to the NUMA node of its GPU.
 """
 import argparse
 import json
