@@ -52,7 +52,14 @@ def _stream_key(dev: torch.device, stream: int):
 
 
 def _stream_lock(dev: torch.device, stream: int) -> threading.RLock:
-    return _lru_get(_STREAM_LOCKS, _stream_key(dev, stream), threading.RLock)
+    """The lock of (device, stream).  Never evicted: replacing a lock somebody holds would hand a second thread a fresh one for the same
+    stream.  (One small object per distinct stream handle the process ever rendered on; the runtime reuses the handles of destroyed streams.)"""
+    key = _stream_key(dev, stream)
+    with _CACHE_LOCK:
+        lock = _STREAM_LOCKS.get(key)
+        if lock is None:
+            lock = _STREAM_LOCKS[key] = threading.RLock()
+        return lock
 
 
 # Scratch lent to the C ABI (GmpiRenderParams.workspace), one per device and stream: a call in flight on another stream must not share it.
@@ -124,13 +131,39 @@ def _ring(dev: torch.device, stream: int) -> _StatusRing:
     key = _stream_key(dev, stream)
     with _CACHE_LOCK:
         ring = _RINGS.get(key)
-        if ring is None:
-            if len(_RINGS) >= _MAX_STREAMS:   # (a ring with pending slots is never dropped: the oldest drained one goes)
-                for k, old in list(_RINGS.items()):
-                    if not old.pending:
-                        del _RINGS[k]
+        if ring is not None:
+            return ring
+        victims = list(_RINGS.items()) if len(_RINGS) >= _MAX_STREAMS else []
+    # At capacity: a ring is dropped only once its pending slots have been looked at -- what another stream's last calls asserted must not
+    # get lost.  First pass: rings whose renders have finished (no waiting); second pass: wait for the oldest ring's renders.  Another
+    # stream's ring is only touched under that stream's lock, taken without blocking (no lock-order cycle between two threads doing this).
+    for block in (False, True):
+        for k, old in victims:
+            lock = _stream_lock(torch.device("cuda", k[0]), k[1])
+            if not lock.acquire(blocking=False):
+                continue
+            try:
+                while old.pending:
+                    before = len(old.pending)
+                    old.retire(block=block)      # (raises what that stream's calls asserted: late, but not lost)
+                    if len(old.pending) == before:
                         break
-            ring = _RINGS[key] = _StatusRing(dev)
+                if not old.pending:
+                    with _CACHE_LOCK:
+                        if _RINGS.get(k) is old:
+                            del _RINGS[k]
+            finally:
+                lock.release()
+            with _CACHE_LOCK:
+                if len(_RINGS) < _MAX_STREAMS:
+                    break
+        with _CACHE_LOCK:
+            if len(_RINGS) < _MAX_STREAMS:
+                break
+    with _CACHE_LOCK:
+        ring = _RINGS.get(key)
+        if ring is None:
+            ring = _RINGS[key] = _StatusRing(dev)   # (over capacity only if every other ring was busy under another thread's lock)
     return ring
 
 
