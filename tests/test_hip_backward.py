@@ -119,6 +119,35 @@ def test_backward_through_renderer_render_pm1_and_expand():
     assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
 
 
+def test_two_renders_then_one_backward_keep_their_own_cameras():
+    """`render()` keeps its ray / eye / z_dir tensors in buffers reused per (B, H, W, stream) -- but not while a graph
+    is being recorded: two calls under grad with DIFFERENT poses followed by one backward must differentiate each graph with its own
+    cameras (a multi-view or consistency loss; the reference's train.py happens to call backward after every render)."""
+    from ml_gmpi_amd import make_renderer
+    dev = torch.device("cuda:0")
+    D, S, B = 4, 32, 2
+    r = make_renderer("FFHQ", n_planes=D, device=dev, on_out_of_plane="raise")
+    base = torch.from_numpy(oracle.synth_rgba(59, (B, D, 4, S, S))).to(dev)
+    poses = [dict(given_yaws=torch.full((B, 1), y), given_pitches=torch.full((B, 1), p_)) for y, p_ in ((0.25, 0.05), (-0.3, -0.1))]
+    g = torch.randn((B, 3, S, S), generator=torch.Generator().manual_seed(5)).to(dev)
+    alone = []
+    for kw in poses:                                   # each graph on its own
+        v = base.clone().requires_grad_(True)
+        (r.render(v, S, S, **kw)[0] * g).sum().backward()
+        alone.append(v.grad.clone())
+    assert float((alone[0] - alone[1]).abs().max()) > 1e-3 * float(alone[0].abs().max())   # (the poses do differ)
+    va, vb = base.clone().requires_grad_(True), base.clone().requires_grad_(True)
+    rgb_a = r.render(va, S, S, **poses[0])[0]
+    rgb_b = r.render(vb, S, S, **poses[1])[0]          # same shape, same stream: would overwrite reused camera buffers
+    ((rgb_a * g).sum() + (rgb_b * g).sum()).backward()
+    for got, want in ((va.grad, alone[0]), (vb.grad, alone[1])):   # (atomic adds: the summation order varies from run to run)
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    with torch.no_grad():                              # (and without a graph the buffers ARE reused: nothing allocated per call)
+        x = r.render(base, S, S, **poses[0])
+        y = r.render(base, S, S, **poses[1])
+    assert x[0].shape == y[0].shape
+
+
 def test_no_gradient_to_geometry_and_no_grad_mode():
     from ml_gmpi_amd import MPI
     rgba, dhw, ray, eye, zd, v2m = _setup(1, 1, 3, 16, 16, 16, 16, seed=47)
