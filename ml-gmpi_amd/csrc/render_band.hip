@@ -9,8 +9,8 @@
 //  * the COMPUTE side is bound by instruction issue and by what a plane step costs besides the pixels: the coordinate chain,
 //    16 taps, bilinear and blend are 55 VALU instructions per pixel and plane (51 of them in the 1.0-1.1 ns class), but a 32 x 16
 //    tile kernel pays 19 VALU + 41 SALU + a barrier per 64 pixels on top (loader, range check, table reads).
-// So: a workgroup of 1024 threads owns a band of sub-blocks of 64 x 8 pixels (struct Geo: bf16 4 sub-blocks x 4 waves x 2 pixels per
-// thread, fp32 2 sub-blocks x 8 waves x 1 pixel per thread -- the texel rows of a band's boxes are 576 bytes either way).  Each
+// So: a workgroup owns a band of sub-blocks of 64 x 8 pixels (struct Geo: bf16 1024 threads = 4 sub-blocks x 4 waves x 2 pixels per
+// thread, fp32 512 threads = 2 sub-blocks x 4 waves x 2 pixels per thread -- the texel rows of a band's boxes are 576 bytes either way).  Each
 // sub-block has its own texel box per plane (a tilted camera shears a 256-pixel band over up to 54 texel rows, a sub-block over
 // 6-14), staged as raw texels, planar [row][channel][x], one DMA item = 16 bytes of a channel row, lane-linear LDS image,
 // exec-masked DMA instructions, zeros padding by the buffer range check, two staging buffers, ONE s_barrier per plane, taps by
@@ -48,15 +48,27 @@ __device__ __forceinline__ void dma16x2(uint32_t voff, uint32_t soff1, const u32
 
 // The band of a workgroup by storage type -- the same LDS budget (two staging buffers of 15 texel rows x 80 texels per sub-block = 76.8 KB, two
 // workgroups per CU) buys
-//   bf16: 4 sub-blocks = 256 x 8 pixels, 4 waves per sub-block, 2 pixels per thread (rows j, j + 4);
-//   fp32: 2 sub-blocks = 128 x 8 pixels, 8 waves per sub-block, 1 pixel per thread -- a texel row of a box is 576 bytes either way.
+//   bf16: 4 sub-blocks = 256 x 8 pixels, 4 waves per sub-block, 2 pixels per thread (rows j, j + 4): 1024 threads;
+//   fp32: 2 sub-blocks = 128 x 8 pixels, 4 waves per sub-block, 2 pixels per thread: 512 threads -- a texel row of a box is 576 bytes either way.
+// Pixels per thread are a build parameter (round 4, profiles/r04_band_variants.txt item 14): with twice the pixels a workgroup has half the waves, i.e.
+// half the per-wave skeleton of a plane step (barrier, DMA issue, record loads) and half the loader lanes per sub-block (5 DMA passes of 3 rows instead
+// of 3 of 6).  fp32 gains 3-4 % from 2 pixels (config 3 with an fp32 volume 1.218 -> 1.184 ms, config 5 3.36 -> 3.23); bf16 LOSES 2 % with 4 (0.800 ->
+// 0.815: four waves per SIMD no longer cover its 32 two-byte taps per pixel pair), so it stays at 2.
+#ifndef GMPI_BAND_PPT16
+#define GMPI_BAND_PPT16 2
+#endif
+#ifndef GMPI_BAND_PPT32
+#define GMPI_BAND_PPT32 2
+#endif
 template <typename TexT> struct Geo {
     static constexpr int kES = static_cast<int>(sizeof(TexT));
     static constexpr int NSB = kES == 2 ? 4 : 2;            // sub-blocks per band
-    static constexpr int PPT = kES == 2 ? 2 : 1;            // pixels per thread: rows j + WPS q of the sub-block (j = wave % WPS)
+    static constexpr int PPT = kES == 2 ? GMPI_BAND_PPT16 : GMPI_BAND_PPT32;  // pixels per thread: rows j + WPS q of the sub-block (j = wave % WPS)
     static constexpr int WPS = SBH / PPT;                   // waves per sub-block
     static constexpr int kSubLanes = 64 * WPS;              // loader lanes per sub-block
-    static_assert(NSB * WPS * 64 == kNT, "waves");
+    static constexpr int kThreads = NSB * kSubLanes;        // threads per workgroup: 1024 as shipped (512 with twice the pixels per thread)
+    static constexpr int kWavesPerSimd = kThreads / 128;    // two workgroups per CU
+    static_assert(kThreads <= kNT && SBH % PPT == 0, "waves");
     static constexpr int kTPI = 16 / kES;                   // texels per 16-byte item
     static constexpr int kCols = kES == 2 ? 10 : 20;        // items per (row, channel) line: 80 texels
     static constexpr int kLineBytes = kCols * 16;
@@ -70,9 +82,9 @@ template <typename TexT> struct Geo {
     // of pass 0 moved down by r * kRPP rows -- one per-lane offset register, the pass in the instruction's scalar offset.
     static constexpr int kRPP = kSubLanes / kIPR;           // 6 rows per pass
     static constexpr int kPassItems = kRPP * kIPR;          // 240 (bf16) / 480 (fp32) active lanes
-    static constexpr int kNP = 3;                           // DMA passes per plane at most
-    static_assert((kMaxRows + kRPP - 1) / kRPP <= kNP, "passes");
-    static constexpr int kOffBytes = kNT * 4;               // per-lane loader offsets (kept in LDS: a VGPR through the plane loop is dearer)
+    static constexpr int kNP = (kMaxRows + kRPP - 1) / kRPP;  // DMA passes per plane at most: 3 as shipped, 5 with half the loader lanes
+    static_assert(kNP == 3 || kNP == 5, "passes");
+    static constexpr int kOffBytes = kThreads * 4;          // per-lane loader offsets (kept in LDS: a VGPR through the plane loop is dearer)
     static constexpr int kLdsBytes = kOffBytes + 2 * kBufBytes;
 };
 static_assert(Geo<bf16_t>::kLdsBytes * 2 <= 160 * 1024 && Geo<f16_t>::kLdsBytes * 2 <= 160 * 1024 && Geo<float>::kLdsBytes * 2 <= 160 * 1024, "2 workgroups per CU");
@@ -105,6 +117,34 @@ __device__ __forceinline__ void dma16x2(uint32_t voff, uint32_t soff1, const u32
                  "s_mov_b64 exec, %5\n\ts_add_i32 m0, %3, %8\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %6 offen lds\n\t"
                  "s_mov_b64 exec, %0"
                  : "=&s"(save) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(m0), "s"(m1), "s"(soff1), "i"(D0), "i"(D0 + STEP)
+                 : "memory", "scc");
+}
+template <int D0, int STEP>
+__device__ __forceinline__ void dma16x4(uint32_t voff, uint32_t s1, uint32_t s2, uint32_t s3, const u32x4& rsrc, uint32_t lds_dst, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3) {
+    uint64_t save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %4\n\ts_add_i32 m0, %3, %11\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                 "s_mov_b64 exec, %5\n\ts_add_i32 m0, %3, %12\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %8 offen lds\n\t"
+                 "s_mov_b64 exec, %6\n\ts_add_i32 m0, %3, %13\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %9 offen lds\n\t"
+                 "s_mov_b64 exec, %7\n\ts_add_i32 m0, %3, %14\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %10 offen lds\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(s1), "s"(s2), "s"(s3),
+                   "i"(D0), "i"(D0 + STEP), "i"(D0 + 2 * STEP), "i"(D0 + 3 * STEP)
+                 : "memory", "scc");
+}
+template <int D0, int STEP>
+__device__ __forceinline__ void dma16x5(uint32_t voff, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t s4, const u32x4& rsrc, uint32_t lds_dst, uint64_t m0, uint64_t m1, uint64_t m2,
+                                        uint64_t m3, uint64_t m4) {
+    uint64_t save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %4\n\ts_add_i32 m0, %3, %13\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+                 "s_mov_b64 exec, %5\n\ts_add_i32 m0, %3, %14\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %9 offen lds\n\t"
+                 "s_mov_b64 exec, %6\n\ts_add_i32 m0, %3, %15\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %10 offen lds\n\t"
+                 "s_mov_b64 exec, %7\n\ts_add_i32 m0, %3, %16\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %11 offen lds\n\t"
+                 "s_mov_b64 exec, %8\n\ts_add_i32 m0, %3, %17\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %12 offen lds\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(m0), "s"(m1), "s"(m2), "s"(m3), "s"(m4), "s"(s1), "s"(s2), "s"(s3), "s"(s4),
+                   "i"(D0), "i"(D0 + STEP), "i"(D0 + 2 * STEP), "i"(D0 + 3 * STEP), "i"(D0 + 4 * STEP)
                  : "memory", "scc");
 }
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -241,11 +281,11 @@ __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const
 }
 
 template <typename TexT, bool AC, bool STRICT, bool CHECK>
-__global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
+__global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
                                                          const uint4* __restrict__ recs, const uint4* __restrict__ pl, const uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kNP = G::kNP;
-    constexpr int NSB = G::NSB, PPT = G::PPT, WPS = G::WPS, kSubLanes = G::kSubLanes;
+    constexpr int NSB = G::NSB, PPT = G::PPT, WPS = G::WPS, kSubLanes = G::kSubLanes, kThreads = G::kThreads;
     constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
     constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
     constexpr bool BF = kES == 2;                              // 16-bit texels (bf16 or fp16): the two-pixel geometry, taps by ds_read_u16_d16_hi
@@ -329,6 +369,7 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         reinterpret_cast<uint32_t*>(smem)[tid] = static_cast<uint32_t>(l_row * s_row + (l_line & 3) * s_chan + kTPI * l_col) * static_cast<uint32_t>(kES);
     }
     const uint32_t pass_off = static_cast<uint32_t>(kRPP * s_row) * static_cast<uint32_t>(kES), pass_off2 = 2 * pass_off;           // per pass
+    const uint32_t pass_off3 = 3 * pass_off, pass_off4 = 4 * pass_off;  // (kNP == 5 only)
     const uint32_t sub_base = tile_base + static_cast<uint32_t>(sb * kSubBytes);
     const uint32_t wave_dst = sub_base + static_cast<uint32_t>(wj) * 1024u;  // pass r: + r * kPassItems * 16
 
@@ -377,7 +418,8 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         //      times per band).  (`three` of plane t is latched before plane t + 1 is issued: the range check of plane t reads it.) ----
         uint64_t m_cur[kNP];
         int dims_cur = 0;
-        bool three = false;  // the box of the plane last issued needs the third pass
+        bool three = false;  // the box of the plane last issued needs the LAST pass (the kNP-th: the third as shipped)
+        int np_cur = kNP - 1;  // kNP == 5: its number of passes (3, 4 or 5)
 #pragma unroll
         for (int r = 0; r < kNP; ++r) m_cur[r] = 0;
 
@@ -393,7 +435,8 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                 if (dims != dims_cur) {
                     const int nq = dims & 31, rows = dims >> 5;
                     dims_cur = dims;
-                    three = rows > 2 * kRPP;
+                    three = rows > (kNP - 1) * kRPP;
+                    np_cur = max((rows + kRPP - 1) / kRPP, 3);
                     int l_col, l_line, l_row;
                     bool l_on;
                     loader_pos(l_col, l_line, l_row, l_on);
@@ -403,16 +446,22 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                         if (abl_noload) m_cur[r] = 0;
                     }
                 }
-                static_assert(kNP == 3, "dma16x3");
-                if (three) dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
-                else dma16x2<U * kBufBytes, kPassItems * 16>(g_off, pass_off, rsrc, wave_dst, m_cur[0], m_cur[1]);
+                if constexpr (kNP == 3) {
+                    if (three) dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
+                    else dma16x2<U * kBufBytes, kPassItems * 16>(g_off, pass_off, rsrc, wave_dst, m_cur[0], m_cur[1]);
+                } else {  // (a pass whose mask is empty still takes its turn on the CU's vector-memory issue path: issue what the box needs)
+                    if (np_cur == 5) dma16x5<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, pass_off3, pass_off4, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2], m_cur[3], m_cur[4]);
+                    else if (np_cur == 4) dma16x4<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, pass_off3, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2], m_cur[3]);
+                    else dma16x3<U * kBufBytes, kPassItems * 16>(g_off, pass_off, pass_off2, rsrc, wave_dst, m_cur[0], m_cur[1], m_cur[2]);
+                }
             } else {  // zeros padding: every lane of the box rows is active, lanes outside the texture get the out-of-range offset
                 const Shape h = shape_unpack(static_cast<uint32_t>(dims));
                 const int rows = h.rows;
                 const uint32_t clo = h.clo, ncol = h.ncol, llo = 4 * h.rlo, nline = 4 * h.nrow;
                 dims_cur = dims;
-                three = rows > 2 * kRPP;
+                three = rows > (kNP - 1) * kRPP;
                 const int npk = (rows + kRPP - 1) / kRPP;
+                np_cur = max(npk, 3);
                 int l_col, l_line, l_row;
                 bool l_on;
                 loader_pos(l_col, l_line, l_row, l_on);
@@ -555,10 +604,11 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
         uint32_t rhh_c, gp_c;
         uint32_t g_off = 0;  // this lane's loader offset: a vector register through the plane loop (round 3 re-read it from LDS behind every barrier)
 #ifdef GMPI_PROF  // (the phase stamps wait for lgkmcnt(0): they would serialise the pipeline they are meant to time)
-        constexpr bool piped = false, piped32 = false;
+        constexpr bool piped = false, piped32 = false, pipedG = false;
 #else
-        constexpr bool piped = BF && !STRICT && PPT == 2;
-        constexpr bool piped32 = !BF && !STRICT && PPT == 1;
+        constexpr bool piped = BF && !STRICT && PPT == 2 && kNP == 3;
+        constexpr bool piped32 = !BF && !STRICT && PPT == 1 && kNP == 3;
+        constexpr bool pipedG = !STRICT && kNP == 5;   // the experiment geometries (twice the pixels per thread, half the waves): the same pipeline, written once for any PPT
 #endif
         auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
             constexpr int U = decltype(ub)::value;
@@ -566,20 +616,41 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
             GMPI_STAMP(0);
             const uint32_t a_it = sub_base + static_cast<uint32_t>(fresh_tid() & (kSubLanes - 1)) * 16u;
             // (loads and their wait in ONE statement unless noted: the compiler may copy an asm load's destination as soon as the statement ends)
-            u32x4 cq0, cq1, cq2;
+            u32x4 cq0, cq1, cq2, cq3, cq4;
             const bool three_cur = three;  // set by the issue of this plane, one step ago
             if (tt + 1 < D && !abl_noissue) issue(Ln, g_off, ic<1 - U>{});
             GMPI_STAMP(3);
             const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
             // tap address constant of this plane and buffer (an integer below 2^24, exact in fp32)
             const float2 rg = make_float2(__uint_as_float(rhh_c), static_cast<float>(static_cast<int>(gp_c) + static_cast<int>(tile_base) + U * kBufBytes));
-            auto check_tail = [&]() {  // the third item of a lane (boxes of more than 2 kRPP rows: rare)
+            auto check_tail = [&]() {  // the last item of a lane (boxes of more than (kNP - 1) kRPP rows: rare)
                 if (three_cur) {
-                    constexpr int kTail = (kSubBytes - 2 * kPassItems * 16) / 16;
+                    constexpr int kTail = (kSubBytes - (kNP - 1) * kPassItems * 16) / 16;
                     const uint32_t a_t = sub_base + static_cast<uint32_t>(min(fresh_tid() & (kSubLanes - 1), kTail - 1)) * 16u;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq2) : "v"(a_t), "i"(U * kBufBytes + 2 * kPassItems * 16));
-                    check_fold(cq2);
+                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq4) : "v"(a_t), "i"(U * kBufBytes + (kNP - 1) * kPassItems * 16));
+                    check_fold(cq4);
                 }
+            };
+            // the read-back of the first kNP - 1 passes: issue (no wait) | land behind N younger LDS operations + fold
+            auto c_issue = [&]() {
+                if constexpr (kNP == 3)
+                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                                 : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
+                else
+                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                                 : "=&v"(cq0), "=&v"(cq1), "=&v"(cq2), "=&v"(cq3)
+                                 : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16), "i"(U * kBufBytes + 2 * kPassItems * 16), "i"(U * kBufBytes + 3 * kPassItems * 16));
+            };
+            auto c_land = [&](auto nb) {
+                constexpr int N = decltype(nb)::value;
+                if constexpr (kNP == 3) {
+                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(cq0), "+v"(cq1) : "i"(N));
+                    check_fold(cq0), check_fold(cq1);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(cq0), "+v"(cq1), "+v"(cq2), "+v"(cq3) : "i"(N));
+                    check_fold(cq0), check_fold(cq1), check_fold(cq2), check_fold(cq3);
+                }
+                check_tail();
             };
             if constexpr (piped) {
                 if (abl_nocomp) {
@@ -670,12 +741,84 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
                     smp[3] = bilerp<false>(__uint_as_float(vb[2].x), __uint_as_float(vb[2].y), __uint_as_float(vb[3].x), __uint_as_float(vb[3].y), f);
                     blend<false>(A[0], smp[0], smp[1], smp[2], smp[3], p0.s, dots[0]);
                 }
+            } else if constexpr (pipedG) {
+                // any PPT: c | A0 B0 | A1 B1 | ... (A = channels R G of a pixel, B = B A); every wait but the last leaves one batch in flight
+                constexpr int NB = BF ? 8 : 4;  // LDS operations per batch
+                if (abl_nocomp) {
+                    if (check_range) {
+                        c_issue();
+                        c_land(ic<0>{});
+                    }
+                } else {
+                    uint32_t ta[8], tb[8];
+                    u32x2_t va[4], vb[4];
+                    Coords pc, pn;
+                    Footprint f;
+                    float smp[4];
+                    auto issueA = [&](const Coords& c) {
+                        if constexpr (BF) taps_issue(ic<0>{}, c.a_tap, ta);
+                        else taps32_issue(ic<0>{}, c.a_tap, c.a_tap + kRowBytes, va);
+                    };
+                    auto issueB = [&](const Coords& c) {
+                        if constexpr (BF) taps_issue(ic<1>{}, c.a_tap, tb);
+                        else taps32_issue(ic<1>{}, c.a_tap, c.a_tap + kRowBytes, vb);
+                    };
+                    auto landA = [&](auto nb) {
+                        if constexpr (BF) {
+                            taps_land(nb, ta);
+                            smp[0] = bilerp<false>(tapf(ta[0]), tapf(ta[1]), tapf(ta[2]), tapf(ta[3]), f);
+                            smp[1] = bilerp<false>(tapf(ta[4]), tapf(ta[5]), tapf(ta[6]), tapf(ta[7]), f);
+                        } else {
+                            taps32_land(nb, va);
+                            smp[0] = bilerp<false>(__uint_as_float(va[0].x), __uint_as_float(va[0].y), __uint_as_float(va[1].x), __uint_as_float(va[1].y), f);
+                            smp[1] = bilerp<false>(__uint_as_float(va[2].x), __uint_as_float(va[2].y), __uint_as_float(va[3].x), __uint_as_float(va[3].y), f);
+                        }
+                        asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));
+                    };
+                    auto landB = [&](auto nb) {
+                        if constexpr (BF) {
+                            taps_land(nb, tb);
+                            smp[2] = bilerp<false>(tapf(tb[0]), tapf(tb[1]), tapf(tb[2]), tapf(tb[3]), f);
+                            smp[3] = bilerp<false>(tapf(tb[4]), tapf(tb[5]), tapf(tb[6]), tapf(tb[7]), f);
+                        } else {
+                            taps32_land(nb, vb);
+                            smp[2] = bilerp<false>(__uint_as_float(vb[0].x), __uint_as_float(vb[0].y), __uint_as_float(vb[1].x), __uint_as_float(vb[1].y), f);
+                            smp[3] = bilerp<false>(__uint_as_float(vb[2].x), __uint_as_float(vb[2].y), __uint_as_float(vb[3].x), __uint_as_float(vb[3].y), f);
+                        }
+                    };
+                    auto px_step = [&](auto qc) {
+                        constexpr int Q = decltype(qc)::value;
+                        constexpr bool more = Q + 1 < PPT;
+                        if constexpr (more) {
+                            coords(Q + 1, rf, rg, pn);  // (the chain of the next pixel issues while this pixel's batches fly)
+                            asm volatile("" : "+v"(pn.s), "+v"(pn.nw), "+v"(pn.ne), "+v"(pn.sw), "+v"(pn.se), "+v"(pn.a_tap));
+                        }
+                        f.nw = pc.nw, f.ne = pc.ne, f.sw = pc.sw, f.se = pc.se;
+                        landA(ic<NB>{});
+                        if constexpr (more) issueA(pn);
+                        landB(ic<(more ? NB : 0)>{});
+                        blend<false>(A[Q], smp[0], smp[1], smp[2], smp[3], pc.s, dots[Q]);
+                        if constexpr (more) {
+                            asm volatile("" : "+v"(A[Q].T), "+v"(A[Q].r), "+v"(A[Q].g), "+v"(A[Q].b), "+v"(A[Q].z));
+                            issueB(pn);
+                            pc = pn;
+                        }
+                    };
+                    if (check_range) c_issue();
+                    coords(0, rf, rg, pc);
+                    issueA(pc);
+                    if (check_range) c_land(ic<NB>{});  // c has landed (A0 may still fly)
+                    issueB(pc);
+                    px_step(ic<0>{});
+                    if constexpr (PPT > 1) px_step(ic<1>{});
+                    if constexpr (PPT > 2) px_step(ic<2>{});
+                    if constexpr (PPT > 3) px_step(ic<3>{});
+                    static_assert(PPT <= 4, "pixel slots");
+                }
             } else {
                 if (check_range) {
-                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                    check_fold(cq0), check_fold(cq1);
-                    check_tail();
+                    c_issue();
+                    c_land(ic<0>{});
                     GMPI_STAMP(2);
                 }
                 if (!abl_nocomp) {
@@ -691,14 +834,14 @@ __global__ __launch_bounds__(kNT, 8) void render_band_kernel(const KParams p, co
             gp_c = Ln.w;  // (Ln is still the record of plane tt + 1)
             Ln = myrec[static_cast<int64_t>(tt + 2) * kRecStep];
             Fc = mypl[(tt + 1) * kPlU4], rhh_c = mypl[(tt + 1) * kPlU4 + 1].x;
-            static_assert(PPT <= 2 && kNP <= 3, "pixel slots / check passes");
+            static_assert(PPT <= 4 && kNP <= 5, "pixel slots / check passes");
         };
         // (the per-pixel state must sit in registers through the plane loop: a reload there is a vector memory operation on the DMA's counter)
 #pragma unroll
         for (int q = 0; q < PPT; ++q)
             asm volatile("" : "+v"(rx[q]), "+v"(ry[q]), "+v"(rz[q]), "+v"(rcp_rz[q]), "+v"(A[q].T), "+v"(A[q].r), "+v"(A[q].g), "+v"(A[q].b), "+v"(A[q].z));
         if (check_range) {  // zero-fill of the staging buffers (see check_fold)
-            for (int i = tid; i < 2 * kBufBytes / 16; i += kNT) reinterpret_cast<uint4*>(smem + G::kOffBytes)[i] = make_uint4(0, 0, 0, 0);
+            for (int i = tid; i < 2 * kBufBytes / 16; i += kThreads) reinterpret_cast<uint4*>(smem + G::kOffBytes)[i] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();  // (also: the loader offsets are in place)
         g_off = reinterpret_cast<const uint32_t*>(smem)[fresh_tid()];
@@ -808,7 +951,7 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
     constexpr int NSB = Geo<TexT>::NSB;
     int bands_x, bands_y, n_bands;
     band_grid(p, NSB, bands_x, bands_y, n_bands);
-    const dim3 grid(xcd_grid_per_group(bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands)), block(kNT);
+    const dim3 grid(xcd_grid_per_group(bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands)), block(Geo<TexT>::kThreads);
     const bool acf = p.flags & 1u;
     const float cx = acf ? static_cast<float>(p.Wt - 1) * 0.5f : static_cast<float>(p.Wt), cy = acf ? static_cast<float>(p.Ht - 1) * 0.5f : static_cast<float>(p.Ht);
     uint32_t* hdr = static_cast<uint32_t*>(p.ws);

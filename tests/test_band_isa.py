@@ -33,7 +33,10 @@ def test_band_kernel_has_no_scratch_and_fits_two_workgroups_per_cu(tmp_path):
         meta = meta[:meta.index(".end_amdhsa_kernel")]
         vgpr = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1))
         lds = int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", meta).group(1))
-        assert vgpr <= 64, (name, vgpr)   # (a private segment may be RESERVED -- a frame object whose accesses were optimised away -- but not used)
+        # bf16 / fp16: 1024 threads, two workgroups per CU = 8 waves per SIMD = 64 registers; fp32: 512 threads (2 pixels per thread, round 4) = 4 waves per
+        # SIMD = 128 registers (the unified file: `next_free_vgpr` counts the accumulation registers the allocator parks values in)
+        fp32 = "render_band_kernelIf" in name
+        assert vgpr <= (128 if fp32 else 64), (name, vgpr)   # (a private segment may be RESERVED -- a frame object whose accesses were optimised away -- but not used)
         assert 2 * lds <= 160 * 1024, (name, lds)
         # the plane loop: one s_barrier per plane step, the DMA and the taps inside it
         assert body.count("s_barrier") >= 2 and "buffer_load_dwordx4" in body and " lds" in body
