@@ -137,6 +137,25 @@ class ViewBatchDriver:
     def __init__(self, renderer, batch: int = 8):
         self.renderer = renderer
         self.batch = int(batch)
+        self._host = {}
+
+    def to_host(self, *tensors: torch.Tensor):
+        """Device tensors -> PINNED host tensors kept by the driver, one asynchronous copy each and one synchronisation.  A fresh pageable
+        `.cpu()` tensor per pass pays the page faults of its allocation on top of the copy (64 uint8 frames of 512^2: 5-9 k frames/s from
+        run to run; 9 k steadily this way).  The buffers are reused by the next call with the same shapes: consume (or copy) them first."""
+        outs = []
+        for i, t in enumerate(tensors):
+            key = (i, tuple(t.shape), t.dtype)
+            buf = self._host.get(key)
+            if buf is None:
+                while len(self._host) >= 8:
+                    self._host.pop(next(iter(self._host)))
+                buf = self._host[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=t.is_cuda)
+            buf.copy_(t, non_blocking=True)
+            outs.append(buf)
+        if tensors and tensors[0].is_cuda:
+            torch.cuda.current_stream(tensors[0].device).synchronize()
+        return tuple(outs)
 
     @torch.no_grad()
     def render_path(self, mpi_rgbas: torch.Tensor, render_size: int, yaws: Sequence[float],

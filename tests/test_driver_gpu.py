@@ -32,6 +32,11 @@ def test_render_path_equals_per_view_renders_and_oracle():
     assert np.abs(out["rgb"][2].cpu().numpy() - (2 * orc["color"][0] - 1)).max() <= 1e-5
     assert np.abs(out["depth"][2].cpu().numpy() - orc["depth"][0]).max() <= 1e-5
     assert np.abs(out["T"][2].cpu().numpy() - orc["T"][0]).max() <= 1e-5
+    # the driver's pinned host buffers: same bytes as a plain copy, the same buffers on the next call
+    h_img, h_dep = drv.to_host(out["img8"], out["dep8"])
+    assert h_img.is_pinned() and not h_img.is_cuda and torch.equal(h_img, out["img8"].cpu()) and torch.equal(h_dep, out["dep8"].cpu())
+    again = drv.to_host(out["img8"], out["dep8"])
+    assert again[0].data_ptr() == h_img.data_ptr() and again[1].data_ptr() == h_dep.data_ptr()
 
 
 def test_render_seeds_and_views_per_mpi_match_expanded_volume():
