@@ -53,3 +53,26 @@ sets = {y: coords(S, 96, y) for y in (0.15, 0.3, 0.45)}
 sets['-0.3/p0.1'] = coords(S, 96, -0.3, 0.1)
 for pad in range(0, 32, 4):
     print('pitch', 160 + pad, 'P', (160 + pad) % 32, {k: round(conflicts(v, 160 + pad, 32, 32, S), 3) for k, v in sets.items()})
+
+
+def conflicts_interleaved(planes, pitch_dw, NB, L, S):
+    """The same with lane l of a wave on pixel 2 * (l % 32) + l // 32 of its 64: a pass of 32 lanes = every other pixel = 32 dwords = all banks."""
+    tot = 0; n = 0
+    perm = np.array([2 * (l % 32) + l // 32 for l in range(64)])
+    for ix0, iy0 in planes:
+        for dx, dy in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            D = ((iy0 + dy) * pitch_dw + ((ix0 + dx) >> 1)).reshape(S, S // 64, 64)[:, :, perm]
+            for p0 in range(0, 64, L):
+                g = D[:, :, p0:p0 + L]
+                bank = g % NB
+                cyc = np.ones(g.shape[:2], dtype=np.int64)
+                for b in range(NB):
+                    vs = np.sort(np.where(bank == b, g, -1), axis=2)
+                    distinct = ((vs[:, :, 1:] != vs[:, :, :-1]) & (vs[:, :, 1:] >= 0)).sum(axis=2) + (vs[:, :, 0] >= 0)
+                    cyc = np.maximum(cyc, distinct)
+                tot += (cyc - 1).sum(); n += cyc.size / (64 // L)
+    return tot / n
+
+
+print('---- lanes interleaved over the 64 pixels (32 banks, 32 lanes per pass, pitch 160 dwords)')
+print({k: (round(conflicts(v, 160, 32, 32, S), 3), round(conflicts_interleaved(v, 160, 32, 32, S), 3)) for k, v in sets.items()})
