@@ -375,8 +375,12 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
 
 #ifdef GMPI_TUNE
     const bool abl_noload = (p.flags & (1u << 16)) != 0, abl_nocomp = (p.flags & (1u << 17)) != 0, abl_noissue = (p.flags & (1u << 18)) != 0;
+    // round 5, the "replay" of the plane step: bit 20 = no workgroup barrier, bit 21 = the records of the first planes stay (no scalar
+    // loads in the loop) (KB_NOCHECK=1 in kbench drops the range check).  With 16 + 18 + 20 + 21 a wave runs the exact instruction stream of its pixels -- chain,
+    // counted waits, 32 two-byte taps, bilinear, blend, the read-back and its fold -- and nothing that ties it to the other fifteen waves.
+    const bool abl_nobar = (p.flags & (1u << 20)) != 0, abl_norec = (p.flags & (1u << 21)) != 0;
 #else
-    constexpr bool abl_noload = false, abl_nocomp = false, abl_noissue = false;
+    constexpr bool abl_noload = false, abl_nocomp = false, abl_noissue = false, abl_nobar = false, abl_norec = false;
 #endif
 
 #ifdef GMPI_PROF  // per-phase shader-clock totals of one wave (status words 8..): barrier | LDS burst | range check | DMA issue | - | pixel 0 | pixel 1
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
 #endif
         auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
             constexpr int U = decltype(ub)::value;
-            wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
+            if (!abl_nobar) wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
             GMPI_STAMP(0);
             const uint32_t a_it = sub_base + static_cast<uint32_t>(fresh_tid() & (kSubLanes - 1)) * 16u;
             // (loads and their wait in ONE statement unless noted: the compiler may copy an asm load's destination as soon as the statement ends)
@@ -831,9 +835,11 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
             }
             // The records of the next step (both tables are padded by two planes of records: no bounds tests), BEHIND the last pixel: the waves
             // that get here first pull the lines into the scalar cache, the workgroup's last wave -- the one the barrier waits for -- hits.
-            gp_c = Ln.w;  // (Ln is still the record of plane tt + 1)
-            Ln = myrec[static_cast<int64_t>(tt + 2) * kRecStep];
-            Fc = mypl[(tt + 1) * kPlU4], rhh_c = mypl[(tt + 1) * kPlU4 + 1].x;
+            if (!abl_norec) {
+                gp_c = Ln.w;  // (Ln is still the record of plane tt + 1)
+                Ln = myrec[static_cast<int64_t>(tt + 2) * kRecStep];
+                Fc = mypl[(tt + 1) * kPlU4], rhh_c = mypl[(tt + 1) * kPlU4 + 1].x;
+            }
             static_assert(PPT <= 4 && kNP <= 5, "pixel slots / check passes");
         };
         // (the per-pixel state must sit in registers through the plane loop: a reload there is a vector memory operation on the DMA's counter)
@@ -1005,7 +1011,7 @@ bool band_variant_supports(const KParams& p, int dtype) {
 hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
 #ifdef GMPI_TUNE  // profiling builds: tune bits 8-9 = ablations (no memory traffic / no compositing)
-    p.flags |= static_cast<uint32_t>((tune >> 8) & 15) << 16;
+    p.flags |= static_cast<uint32_t>((tune >> 8) & 127) << 16;
 #else
     (void)tune;
 #endif
