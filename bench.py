@@ -62,6 +62,16 @@ WORKLOADS = {
 }
 
 
+# G-step shapes of the reference's curriculum (curriculums.py:89-91: 32 planes; batch 8 at 256^2, 4 at 512^2 and 1024^2; train.py:740-779: render
+# with grad, loss, backward): forward + gradient w.r.t. the RGBA volume, fp32.
+TRAIN_WORKLOADS = {
+    # name: (preset, S, D, batch, description)
+    "train256": ("FFHQ", 256, 32, 8, "G-step render 256x256, 32 planes, batch 8, fp32: forward + backward w.r.t. the RGBA volume"),
+    "train512": ("FFHQ", 512, 32, 4, "G-step render 512x512, 32 planes, batch 4, fp32: forward + backward w.r.t. the RGBA volume"),
+    "train1024": ("FFHQ", 1024, 32, 4, "G-step render 1024x1024, 32 planes, batch 4, fp32: forward + backward w.r.t. the RGBA volume"),
+}
+
+
 def algorithmic_bytes(n_views, D, S, s_in, want_T):
     return n_views * D * 4 * S * S * s_in + n_views * S * S * 12 + n_views * S * S * 4 * (4 + (1 if want_T else 0))
 
@@ -85,7 +95,11 @@ def footprint_bytes(ray, eye, dhw, S, s_in, want_T):
 
 
 def cpu_baseline(preset, S, D, dtype, budget_s=20.0):
-    """Oracle (OpenMP) on ONE view of the workload shape, repeated until ~budget_s of CPU wall time."""
+    """The CPU side of the line, on ONE view of the workload shape, ~budget_s of CPU wall time in total:
+      headline entry (kind "reference-ops"): the reference's own op chain (MPIRenderer.render -> MPI.forward -> homography: the same PyTorch CPU
+        calls in the same order, oracle/torch_ops.py, pinned to fixtures made by the reference itself) -- the reference is not on the GPU box,
+        its ops are; best of a small sweep of intra-op thread counts, `cores` = the count that won;
+      nested `port`: the repo's own restatement (oracle/mpi_oracle.c, OpenMP over all host threads) -- what a hand-written CPU renderer reaches."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
     from ml_gmpi_amd.renderer import MPIRenderer, PRESETS
@@ -112,13 +126,12 @@ def cpu_baseline(preset, S, D, dtype, budget_s=20.0):
         oracle.render(*args, threads=True)
         best = min(best, time.perf_counter() - t1)
         reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 20:
+        if time.perf_counter() - t0 > 0.35 * budget_s or reps >= 20:
             break
-    res = dict(value=round(S * S * D / best / 1e6, 2), unit="Mpix*planes/s", cores=oracle.num_threads(True),
-               kind="port", sample=f"1 view {S}x{S}x{D} ({dtype} values), best of {reps} runs of oracle/mpi_oracle.c (OpenMP)",
-               views_per_s=round(1.0 / best, 4))
-    # second leg: the reference's own op chain (MPIRenderer.render -> MPI.forward -> homography as the same PyTorch calls,
-    # oracle/torch_ops.py; the reference itself is not on the GPU box), all host cores, one view, warm-up + best of <= 3
+    port = dict(value=round(S * S * D / best / 1e6, 2), unit="Mpix*planes/s", cores=oracle.num_threads(True),
+                kind="port", sample=f"1 view {S}x{S}x{D} ({dtype} values), best of {reps} runs of oracle/mpi_oracle.c (OpenMP)",
+                views_per_s=round(1.0 / best, 4))
+    # the reference's own op chain, all host cores available, one view, warm-up + best of <= 2 per thread count
     try:
         import torch_ops
         nproc = os.cpu_count() or 1
@@ -143,14 +156,14 @@ def cpu_baseline(preset, S, D, dtype, budget_s=20.0):
                     break
         nthreads = min(sweep, key=sweep.get)
         best_ops = sweep[nthreads]
-        res["reference_ops"] = dict(value=round(S * S * D / best_ops / 1e6, 2), unit="Mpix*planes/s", cores=nthreads, kind="reference-ops",
-                                    sample=f"1 view {S}x{S}x{D}: the reference's op chain (mpi_renderer.py:444-467, mpi.py:60-153, 321-436) "
-                                           "as the same PyTorch CPU calls, oracle/torch_ops.py; best of the thread counts in `thread_sweep`",
-                                    thread_sweep={str(k): round(S * S * D / v / 1e6, 2) for k, v in sweep.items()}, host_cores=nproc,
-                                    views_per_s=round(1.0 / best_ops, 4))
-    except Exception as e:  # memory (10 GB per 1024^2 x 96 view) or a missing module must not cost the bench line
-        res["reference_ops"] = dict(error=str(e)[:200])
-    return res
+        return dict(value=round(S * S * D / best_ops / 1e6, 2), unit="Mpix*planes/s", cores=nthreads, kind="reference-ops",
+                    sample=f"1 view {S}x{S}x{D} ({dtype} values): the reference's op chain (mpi_renderer.py:444-467, mpi.py:60-153, 321-436) "
+                           "as the same PyTorch CPU calls, oracle/torch_ops.py; best of the thread counts in `thread_sweep`",
+                    thread_sweep={str(k): round(S * S * D / v / 1e6, 2) for k, v in sweep.items()}, host_cores=nproc,
+                    views_per_s=round(1.0 / best_ops, 4), port=port)
+    except Exception as e:  # memory (10 GB per 1024^2 x 96 view) or a missing module must not cost the bench line: the port stands in
+        port["reference_ops_error"] = str(e)[:200]
+        return port
 
 
 def run_video(a, dev, rank, world, use_dist):
@@ -241,6 +254,133 @@ def run_video(a, dev, rank, world, use_dist):
                 "batched_driver": {"views_per_s": round(views / t_batch, 1), "ms_per_view": round(t_batch / views * world * 1e3, 4), "batch": 8,
                                    "what": "ViewBatchDriver.render_path: 8 views per launch, uint8 epilogue on the device, one copy per pass into pinned host buffers"},
                 "frames_identical": bool(same), "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_train(a, dev, rank, world, use_dist):
+    """--workload train256 | train512 | train1024: the render of the reference's G-step (train.py:740-779: `MPIRenderer.render` on the generator's
+    RGBA volume under autograd, a loss on the frames, `.backward()`), at the curriculum's shapes (curriculums.py:89-91: 32 planes, batch 8 / 4 / 4).
+    A "step" = forward launch (colour, depth, transmittance) + zero-fill of the gradient volume + `gmpi_mpi_render_backward_launch`, exactly what
+    `hip_mpi._RenderFunction` enqueues (driven here through the product's own autograd bridge: `render()` on a volume that requires grad, then
+    `torch.autograd.backward` with fixed upstream gradients).  Each part is also timed alone with HIP events.
+    Algorithmic bytes of the step: volume read by the forward + volume read by the backward + gradient volume written (fp32, 16 B per texel and
+    sweep) + per pixel: rays 12 + frames out 20 (forward), rays 12 + upstream gradients 16 + transmittance 4 (backward).  The zero-fill the C ABI
+    asks of the caller and the read half of the atomics' read-modify-write are traffic, not algorithm: they show in `traffic`, not in `achieved`."""
+    import ctypes
+    import ml_gmpi_amd
+    from ml_gmpi_amd import _lib
+    preset, S, D, B, desc = TRAIN_WORKLOADS[a.workload]
+    r = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=a.variant, on_out_of_plane="raise")
+    r.set_cam(r.cam_fov, S, S)
+    g = torch.Generator(device=dev).manual_seed(7000 + rank)
+    rgba = torch.rand((B, D, 4, S, S), device=dev, generator=g)
+    rgba[:, -1, 3] = 1.0
+    rgba.requires_grad_(True)
+    g_color = torch.randn((B, 3, S, S), device=dev, generator=g)
+    g_depth = torch.randn((B, 1, S, S), device=dev, generator=g)
+    torch.manual_seed(3)
+    cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    infos = dict(zip(["batch_yaws", "batch_pitches", "batch_tf_c2w", "batch_ray_dir", "batch_eye_pos", "batch_z_dir"], cam))
+
+    def step():
+        rgba.grad = None
+        color, depth, _, _ = r.render(rgba, S, S, given_cam_infos=infos, defer_status=True)
+        torch.autograd.backward([color, depth], [g_color, g_depth])
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < a.prewarm_ms:
+        step()
+        torch.cuda.synchronize(dev)
+    for _ in range(a.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for e0, e1 in ev:
+        e0.record(); step(); e1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / a.steps
+    grad_ref = rgba.grad.detach().clone()
+
+    # ---- the parts alone, through the C ABI (what the bridge enqueues), HIP events around each ----
+    lib = _lib.load_library()
+    ray, eye, zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+    dhw = r._dhw_on_device().expand(B, -1, -1).contiguous()
+    out = dict(color=torch.empty((B, 3, S, S), device=dev), depth=torch.empty((B, 1, S, S), device=dev), T=torch.empty((B, 1, S, S), device=dev))
+    status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+    vol = rgba.detach()
+
+    def fwd():
+        return r.mpi.render_views(vol, dhw, ray, eye, zd, views_per_mpi=1, check_last_plane=True, out_pm1=True, want_transmittance=True,
+                                  status=status, defer_status=True, out=out, _in_autograd_fn=True)
+    res = fwd()
+    pstruct, keep = res["_bwd"]
+    pstruct.rgb_out = pstruct.depth_out = pstruct.status = None
+    grad = torch.zeros_like(vol)
+    gstride = (ctypes.c_int64 * 5)(*grad.stride())
+    cs = torch.cuda.current_stream(dev).cuda_stream
+
+    def bwd():
+        _lib.check(lib.gmpi_mpi_render_backward_launch(ctypes.byref(pstruct), g_color.data_ptr(), g_depth.data_ptr(), grad.data_ptr(), gstride, cs),
+                   "gmpi_mpi_render_backward_launch")
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for e0, e1 in evs:
+            e0.record(); fn(); e1.record()
+        torch.cuda.synchronize(dev)
+        return sum(e0.elapsed_time(e1) for e0, e1 in evs) / n
+    with torch.no_grad():
+        fwd_ms, zero_ms, bwd_ms = timed(fwd), timed(grad.zero_), timed(bwd)
+        grad.zero_(); bwd()
+        torch.cuda.synchronize(dev)
+        same = float((grad - grad_ref).abs().max() / grad_ref.abs().max())   # (atomics: the order of the adds differs from run to run)
+    r.mpi.raise_on_status(status)
+
+    t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t[0]), float(t[1])
+    if rank == 0:
+        vol_b = B * D * 4 * S * S * 4
+        pix = B * S * S
+        ab_fwd, ab_bwd = vol_b + pix * (12 + 20), 2 * vol_b + pix * (12 + 16 + 4)
+        step_ms = max(kern_ms, elapsed / a.steps * 1e3)
+        ach = (ab_fwd + ab_bwd) / (step_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.isfile(prof):
+            try:
+                pj = json.load(open(prof))
+                if pj.get("source_hash") == _lib.source_hash():
+                    traffic = (pj.get("workloads", {}).get(a.workload) or {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                pass
+        line = {"metric": "Mpix*planes/s", "value": round(B * world * S * S * D * a.steps / elapsed / 1e6, 1), "unit": "Mpix*planes/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": desc + " (curriculums.py:89-91, train.py:740-779)", "name": a.workload, "views_per_gpu": B, "H": S, "W": S, "planes": D,
+                           "rgba_storage": "f32", "variant": a.variant, "parallelism": f"batch sharded x{world}", "step": "forward + zero-fill + backward, via autograd"},
+                "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                             "priced_on_ms": round(step_ms, 4), "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": ab_fwd + ab_bwd, "traffic": traffic,
+                             "parts": {"forward_ms": round(fwd_ms, 4), "forward_frac": round(ab_fwd / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "grad_zero_fill_ms": round(zero_ms, 4),
+                                       "backward_ms": round(bwd_ms, 4), "backward_frac": round(ab_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "backward_algorithmic_bytes": ab_bwd, "what": "each part alone: 20 launches, HIP events on the launch stream"}},
+                "backward_repeatability": {"max_abs_diff_over_max_grad": float(f"{same:.3e}"), "what": "two runs of the backward (atomic adds in a different order)"},
+                "cpu_baseline": None}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
@@ -413,12 +553,103 @@ def pose_sweep(r, rgba, dhw, n_views, vpm, want_T, S, draws, out, status, seed0=
                 views_off_band_share=None if n_total == 0 else round(off_band / n_total, 4))
 
 
+class Workload:
+    """One render workload set up on a device: synthetic volume(s) resident in HBM, the camera tensors of one pose draw, output buffers, and
+    `step()` = ONE pass of the hot path (one `gmpi_mpi_render_launch`) over the batch."""
+
+    def __init__(self, name, dev, rank=0, world=1, variant="auto", strict=False, dry=False, dry_size=64):
+        import ml_gmpi_amd
+        from ml_gmpi_amd import _lib
+        preset, S, D, n_views, dtype, want_T, desc = WORKLOADS[name]
+        if dry:
+            S, D = dry_size, min(D, 8)
+        self.name, self.preset, self.S, self.D, self.n_views, self.dtype, self.want_T, self.desc = name, preset, S, D, n_views, dtype, want_T, desc
+        self.variant, self.strict, self.dev = variant, strict, dev
+        r = self.r = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=variant, strict_order=strict,
+                                               on_out_of_plane="raise", **({"ray_backend": "torch"} if dry else {}))
+        r.set_cam(r.cam_fov, S, S)
+        # ---- synthetic inputs, resident in HBM ----
+        n_mpis = 1 if name == "cfg4" else n_views
+        # config 4 = ONE MPI rendered along a camera path by all ranks: the same volume everywhere; the others: own seeds per rank
+        g = torch.Generator(device=dev).manual_seed(1000 * 3 + (0 if name == "cfg4" else rank))
+        rgba = torch.empty((n_mpis, D, 4, S, S), device=dev, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
+        for i in range(n_mpis):  # per-MPI fill keeps the transient fp32 copy small
+            rgba[i] = torch.rand((D, 4, S, S), device=dev, generator=g).to(rgba.dtype)
+        rgba[:, -1, 3] = 1.0  # background_alpha_full (networks_cond_on_pos_enc.py:1307-1310)
+        self.rgba = rgba
+        # camera poses: the same draw from the dataset's pose distribution on every rank (seed 3) -- the volumes differ per rank, the
+        # per-GPU work does not (kernel time depends on camera tilt by a few per cent: with per-rank pose seeds the max-over-ranks
+        # time of a weak-scaling run would measure pose luck, not scaling)
+        torch.manual_seed(3)
+        if name == "cfg4":  # video path: yaw sweep, pitch 0 (render_video.py:236-237), this rank's 8 of 8 * world views
+            import numpy as np
+            yaw = np.linspace(0.5, -0.5, 8 * world)[rank::world]
+            cam = r.sample_cam_poses(n_views, 0, 0, 0, 0, False, given_yaws=torch.tensor(yaw, dtype=torch.float32).view(-1, 1),
+                                     given_pitches=torch.zeros(n_views, 1))
+        else:
+            cam = r.sample_cam_poses(n_views, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+        self.ray, self.eye, self.zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+        self.dhw = r._dhw_on_device().expand(n_mpis, -1, -1).contiguous()
+        self.vpm = n_views if name == "cfg4" else 1
+        self.out = dict(color=torch.empty((n_views, 3, S, S), device=dev), depth=torch.empty((n_views, 1, S, S), device=dev))
+        if want_T:
+            self.out["T"] = torch.empty((n_views, 1, S, S), device=dev)
+        self.status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        self.hints = pose_hints(self.zd)   # (what MPIRenderer.render passes for these poses: GMPI_FLAG_HINT_FRONTAL / _TILTED, advisory)
+        self.s_in = 2 if dtype == "bf16" else 4
+        self.abytes = algorithmic_bytes(n_views, D, S, self.s_in, want_T)
+
+    def step(self):
+        self.r.mpi.render_views(self.rgba, self.dhw, self.ray, self.eye, self.zd, views_per_mpi=self.vpm, check_last_plane=True, out_pm1=True,
+                                want_transmittance=self.want_T, status=self.status, defer_status=True, out=self.out, **self.hints)
+
+    def parity(self):
+        return parity_block(self.r, self.rgba, self.dhw, self.ray, self.eye, self.zd, self.vpm, self.want_T, self.S)
+
+
+def companion_lines(a, dev, main_name):
+    """Rank 0, N = 1, OUTSIDE the timed region: the configurations that otherwise have no driver-run witness -- config 3 with an fp32 volume (the
+    1024^2 x 96 variant whose kernel is memory-side bound), config 2 (BASELINE configs[1]), and config 3 in strict-order mode (the bit-identical
+    arithmetic the parity tests run).  Each: its own tensors, 5 warm-up + 20 launches with a HIP-event pair around every launch on the launch
+    stream (the GPU is at its busy clocks: the timed steps have just run), mean of the 20; frac = algorithmic bytes / mean / 8 TB/s; and the same
+    oracle comparison as the headline's `parity` block.  Not `value`; a witness."""
+    res = {}
+    for key, name, strict in (("cfg3_f32", "cfg3_f32", False), ("cfg2", "cfg2", False), ("cfg3_strict", "cfg3", True)):
+        if name == main_name and not strict:
+            continue
+        try:
+            w = Workload(name, dev, variant=a.variant, strict=strict)
+            with torch.no_grad():
+                for _ in range(5):
+                    w.step()
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+                for e0, e1 in evs:
+                    e0.record(); w.step(); e1.record()
+                torch.cuda.synchronize(dev)
+                w.r.mpi.raise_on_status(w.status)
+                ms = [e0.elapsed_time(e1) for e0, e1 in evs]
+                mean = sum(ms) / len(ms)
+                ent = dict(workload=w.desc + (", strict-order arithmetic" if strict else ""), ms=round(mean, 4), min_ms=round(min(ms), 4),
+                           launches=len(ms), algorithmic_bytes_per_launch=w.abytes, frac=round(w.abytes / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           mpix_planes_per_s=round(w.n_views * w.S * w.S * w.D / (mean * 1e-3) / 1e6, 1))
+                if not a.no_parity:
+                    par = w.parity()
+                    ent["parity_ok"] = par["ok"]
+                    ent["parity"] = {k: par[k] for k in ("strict_bit_exact", "max_abs_err_color", "max_abs_err_depth")}
+            res[key] = ent
+            del w
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001 -- a companion must not cost the headline line
+            res[key] = dict(error=f"{type(e).__name__}: {e}"[:300])
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["video"])
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS) + ["video"] + sorted(TRAIN_WORKLOADS))
     ap.add_argument("--variant", default="auto", choices=["auto", "gather", "lds", "wave", "band"])
     ap.add_argument("--strict", action="store_true", help="strict-order arithmetic (bit-identical to the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -426,12 +657,19 @@ def main():
     ap.add_argument("--dry-size", type=int, default=64, help="image / texture size of a --dry-run (the volumes live in host memory)")
     ap.add_argument("--numa-pin", action="store_true", help="pin each rank's host threads to the NUMA node of its GPU (mapping printed in the line)")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle comparison of the timed launch (rank 0, outside the timed region)")
+    ap.add_argument("--no-companions", action="store_true", help="skip the `companions` block (cfg3_f32 / cfg2 / cfg3 strict, rank 0, N = 1, outside the timed region)")
     ap.add_argument("--pose-draws", type=int, default=32, help="draws of the pose distribution in the `pose_sweep` block (0 = skip)")
+    ap.add_argument("--profile-clean", action="store_true",
+                    help="for rocprofv3 (tools/prof.sh): the render kernels are launched W + K times and never else -- the clock ramp runs on another "
+                         "kernel (the stream probe), no parity / pose sweep / end-to-end / companions / CPU baseline -- so that the average of the "
+                         "kernel-trace CSV IS roofline.kernel_ms")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="untimed render launches for this long before the W warm-up steps: a GPU coming from idle needs ~0.1 s to reach "
                          "its busy clocks (20 steps are only 23 ms of work); 0 disables")
     a = ap.parse_args()
+    if a.profile_clean:
+        a.no_parity, a.pose_draws, a.no_cpu_baseline, a.no_companions = True, 0, True, True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -461,7 +699,7 @@ def main():
     if dry:
         dry_lib = _DryLibrary()
         _lib.load_library = lambda: dry_lib
-        a.no_parity, a.pose_draws, a.no_cpu_baseline, a.prewarm_ms = True, 0, True, 0.0
+        a.no_parity, a.pose_draws, a.no_cpu_baseline, a.prewarm_ms, a.no_companions = True, 0, True, 0.0, True
     Event = _WallEvent if dry else torch.cuda.Event
 
     def sync():
@@ -471,44 +709,20 @@ def main():
     if a.workload == "video":
         assert not dry, "--dry-run covers the render workloads"
         return run_video(a, dev, rank, world, use_dist)
-    preset, S, D, n_views, dtype, want_T, desc = WORKLOADS[a.workload]
-    if dry:
-        S, D = a.dry_size, min(D, 8)
-    r = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=a.variant, strict_order=a.strict,
-                                  on_out_of_plane="raise", **({"ray_backend": "torch"} if dry else {}))
-    r.set_cam(r.cam_fov, S, S)
-    # ---- synthetic inputs, resident in HBM --------------------------------------------------------
-    n_mpis = 1 if a.workload == "cfg4" else n_views
-    # config 4 = ONE MPI rendered along a camera path by all ranks: the same volume everywhere; the others: own seeds per rank
-    g = torch.Generator(device=dev).manual_seed(1000 * 3 + (0 if a.workload == "cfg4" else rank))
-    rgba = torch.empty((n_mpis, D, 4, S, S), device=dev, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32)
-    for i in range(n_mpis):  # per-MPI fill keeps the transient fp32 copy small
-        rgba[i] = torch.rand((D, 4, S, S), device=dev, generator=g).to(rgba.dtype)
-    rgba[:, -1, 3] = 1.0  # background_alpha_full (networks_cond_on_pos_enc.py:1307-1310)
-    # camera poses: the same draw from the dataset's pose distribution on every rank (seed 3) -- the volumes differ per rank, the
-    # per-GPU work does not (kernel time depends on camera tilt by a few per cent: with per-rank pose seeds the max-over-ranks
-    # time of a weak-scaling run would measure pose luck, not scaling)
-    torch.manual_seed(3)
-    if a.workload == "cfg4":  # video path: yaw sweep, pitch 0 (render_video.py:236-237), this rank's 8 of 64 views
-        import numpy as np
-        yaw = np.linspace(0.5, -0.5, 8 * world)[rank::world]
-        cam = r.sample_cam_poses(n_views, 0, 0, 0, 0, False, given_yaws=torch.tensor(yaw, dtype=torch.float32).view(-1, 1),
-                                 given_pitches=torch.zeros(n_views, 1))
-    else:
-        cam = r.sample_cam_poses(n_views, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
-    ray, eye, zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
-    dhw = r._dhw_on_device().expand(n_mpis, -1, -1).contiguous()
-    vpm = n_views if a.workload == "cfg4" else 1
-    out = dict(color=torch.empty((n_views, 3, S, S), device=dev), depth=torch.empty((n_views, 1, S, S), device=dev))
-    if want_T:
-        out["T"] = torch.empty((n_views, 1, S, S), device=dev)
-    status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+    if a.workload in TRAIN_WORKLOADS:
+        assert not dry, "--dry-run covers the render workloads"
+        return run_train(a, dev, rank, world, use_dist)
+    w = Workload(a.workload, dev, rank, world, a.variant, a.strict, dry, a.dry_size)
+    r, rgba, dhw, ray, eye, zd, vpm, out, status = w.r, w.rgba, w.dhw, w.ray, w.eye, w.zd, w.vpm, w.out, w.status
+    preset, S, D, n_views, dtype, want_T, desc = w.preset, w.S, w.D, w.n_views, w.dtype, w.want_T, w.desc
+    step = w.step
+    lib = _lib.load_library()
+    vol_bytes = rgba.numel() * rgba.element_size()
+    probe_status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)  # (the probes' own words)
+    cs = 0 if dry else torch.cuda.current_stream(dev).cuda_stream
 
-    hints = pose_hints(zd)   # (what MPIRenderer.render passes for these poses: GMPI_FLAG_HINT_FRONTAL / _TILTED, advisory)
-
-    def step():
-        r.mpi.render_views(rgba, dhw, ray, eye, zd, views_per_mpi=vpm, check_last_plane=True, out_pm1=True,
-                           want_transmittance=want_T, status=status, defer_status=True, out=out, **hints)
+    def probe():
+        _lib.check(lib.gmpi_stream_probe_launch(rgba.data_ptr(), vol_bytes, probe_status.data_ptr(), cs), "gmpi_stream_probe_launch")
 
     def fence():
         sync()
@@ -516,12 +730,13 @@ def main():
             dist.barrier()
         sync()
 
+    e2e = None
     with torch.no_grad():
         if a.prewarm_ms > 0:  # clock ramp (untimed, before the W warm-up steps)
             t_pre = time.perf_counter()
             while (time.perf_counter() - t_pre) * 1e3 < a.prewarm_ms:
                 for _ in range(8):
-                    step()
+                    probe() if a.profile_clean else step()
                 sync()
         for _ in range(a.warmup):
             step()
@@ -535,61 +750,69 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         r.mpi.raise_on_status(status)  # asserts of all steps, one read-back
-        # end-to-end MPIRenderer.render(): pose sampling on the host + rays + launch + status sync
-        r.render(rgba, S, S, views_per_mpi=vpm)  # warm-up of the pose/ray path (first call loads its kernels)
-        e2e = []
-        for _ in range(24):  # every call draws fresh poses: the mean and the worst call are reported (a median would hide the tilted draws)
+        if not a.profile_clean:
+            # end-to-end MPIRenderer.render() as a caller gets it by default: pose sampling on the host + rays + launch + the status read-back
+            # in the call (status_mode="sync": the reference's assertion timing)
+            r.render(rgba, S, S, views_per_mpi=vpm)  # warm-up of the pose/ray path (first call loads its kernels)
+            e2e_t = []
+            for _ in range(24):  # every call draws fresh poses: the mean and the worst call are reported (a median would hide the tilted draws)
+                sync()
+                t1 = time.perf_counter()
+                r.render(rgba, S, S, views_per_mpi=vpm)
+                sync()
+                e2e_t.append((time.perf_counter() - t1) * 1e3)
+            # ... and back to back with the LAGGED status check (opt-in, defer_status="lag"): the host runs ahead of the device, one sync at the end
             sync()
             t1 = time.perf_counter()
-            r.render(rgba, S, S, views_per_mpi=vpm)
+            for _ in range(24):
+                r.render(rgba, S, S, views_per_mpi=vpm, defer_status="lag")
             sync()
-            e2e.append((time.perf_counter() - t1) * 1e3)
-        e2e_ms, e2e_max_ms = sum(e2e) / len(e2e), max(e2e)
-        # ... and back to back, one sync at the end (a driver loop: the host runs ahead of the device, status checks lag by a call)
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(24):
+            e2e_b2b_ms = (time.perf_counter() - t1) * 1e3 / 24
+            ml_gmpi_amd.flush_status()  # (the lagged calls' status bits: looked at now)
+            # the same with the poses of the calls drawn ahead of time (MPIRenderer.prefetch_poses): what is left between two
+            # launches is the ray kernel, the marshalling of the parameter struct and the status read-back
+            r.prefetch_poses(8, n_views)
             r.render(rgba, S, S, views_per_mpi=vpm)
-        sync()
-        e2e_b2b_ms = (time.perf_counter() - t1) * 1e3 / 24
-        # the same with the poses of the calls drawn ahead of time (MPIRenderer.prefetch_poses): what is left between two
-        # launches is the ray kernel, the marshalling of the parameter struct and the status read-back
-        r.prefetch_poses(8, n_views)
-        r.render(rgba, S, S, views_per_mpi=vpm)
-        e2e_pre = []
-        for _ in range(7):
-            sync()
-            t1 = time.perf_counter()
-            r.render(rgba, S, S, views_per_mpi=vpm)
-            sync()
-            e2e_pre.append((time.perf_counter() - t1) * 1e3)
-        e2e_pre_ms = sorted(e2e_pre)[len(e2e_pre) // 2]
-        ml_gmpi_amd.flush_status()  # (render() checks its status bits a call late: the last ones now)
+            e2e_pre = []
+            for _ in range(7):
+                sync()
+                t1 = time.perf_counter()
+                r.render(rgba, S, S, views_per_mpi=vpm)
+                sync()
+                e2e_pre.append((time.perf_counter() - t1) * 1e3)
+            e2e = dict(mean=sum(e2e_t) / len(e2e_t), max=max(e2e_t), b2b=e2e_b2b_ms, pre=sorted(e2e_pre)[len(e2e_pre) // 2])
         sweep = None
         if a.pose_draws > 0 and a.workload != "cfg4":  # (config 4's poses are a fixed yaw sweep, not a draw)
             sweep = pose_sweep(r, rgba, dhw, n_views, vpm, want_T, S, a.pose_draws, out, status)
         # final gather of the finished frames (the only collective of the job)
-        gather_ms = None
+        gather_ms = gather_bytes = None
         if use_dist:
             frames = torch.cat([out["color"], out["depth"]] + ([out["T"]] if want_T else []), dim=1)
             buf = torch.empty((world,) + tuple(frames.shape), device=dev)
+            dist.all_gather_into_tensor(buf.view(-1, *frames.shape[1:]), frames)   # (first call: communicator set-up, untimed)
             fence()
             tg = time.perf_counter()
             dist.all_gather_into_tensor(buf.view(-1, *frames.shape[1:]), frames)
             fence()
             gather_ms = (time.perf_counter() - tg) * 1e3
+            gather_bytes = buf.numel() * buf.element_size()
 
     kern_ms = sum(s.elapsed_time(e) for s, e in ev) / a.steps
     t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
+    per_rank = None
     if use_dist:
+        mine = torch.tensor([elapsed / a.steps * 1e3], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)            # straggler visibility: every rank's own wall time per step
+        per_rank = [float(x[0]) for x in allr]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
 
     if rank == 0:
         units_per_step = n_views * S * S * D * world  # pixel*planes, all ranks
         value = units_per_step * a.steps / elapsed / 1e6
-        s_in = 2 if dtype == "bf16" else 4
-        abytes = algorithmic_bytes(n_views, D, S, s_in, want_T)
+        s_in = w.s_in
+        abytes = w.abytes
         # the roofline is priced on the LARGER of the two clocks (event-timed launches, wall time per step): a launch sequence whose
         # events under-report (queueing, several kernels per step) must not raise the fraction
         step_ms = elapsed / a.steps * 1e3
@@ -620,10 +843,6 @@ def main():
         # streaming-read ceiling of THIS box, measured in-run: one read-only pass over the same volume with the fastest read pattern of
         # profiles/r03_calibration.txt (gmpi_stream_probe_launch: non-temporal dword loads); the exhaustive range check -- the product's own
         # streaming pass over the volume, install()'s default assertion -- is timed next to it
-        vol_bytes = rgba.numel() * rgba.element_size()
-        lib = _lib.load_library()
-        probe_status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)  # (its own words: the render's were read above)
-        cs = 0 if dry else torch.cuda.current_stream(dev).cuda_stream
 
         def timed(launch):
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
@@ -637,15 +856,18 @@ def main():
         if dry:
             stream_gbs = range_check_gbs = 1.0
         else:
-            stream_gbs = timed(lambda: _lib.check(lib.gmpi_stream_probe_launch(rgba.data_ptr(), vol_bytes, probe_status.data_ptr(), cs), "gmpi_stream_probe_launch"))
+            stream_gbs = timed(probe)
             range_check_gbs = timed(lambda: _lib.check(lib.gmpi_rgba_range_check_launch(rgba.data_ptr(), {"f32": 0, "bf16": 1}[dtype], rgba.numel(),
                                                                                          probe_status.data_ptr(), cs), "gmpi_rgba_range_check_launch"))
+        baseline_cfg = {"cfg4": "BASELINE configs[3]: 64 camera-path views of ONE 512^2 x 96 MPI over 8 GPUs = 8 views per GPU",
+                        "cfg5": "BASELINE configs[4]: 32 seeds of 1024^2 x 256 + transmittance over 8 GPUs = 4 seeds per GPU"}.get(a.workload)
         line = {
             "metric": "Mpix*planes/s", "value": round(value, 1), "unit": "Mpix*planes/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "DRY RUN: no GPU, launches counted not executed -- no number of this line means anything" if dry else "synthetic",
-            "config": {"workload": desc, "name": a.workload, "views_per_gpu": n_views, "H": S, "W": S, "planes": D,
+            "config": {"workload": desc + (f" ({baseline_cfg}; this job: {n_views * world} views on {world} GPU(s))" if baseline_cfg else ""),
+                       "name": a.workload, "views_per_gpu": n_views, "views_total": n_views * world, "H": S, "W": S, "planes": D,
                        "rgba_storage": dtype, "variant": a.variant, "strict_order": a.strict,
                        "outputs": "rgb+depth" + ("+transmittance" if want_T else ""), "parallelism": f"views sharded x{world}",
                        "poses": "cfg4: yaw sweep 0.5..-0.5 split over the ranks" if a.workload == "cfg4" else "truncated-gaussian draw (seed 3) on every rank"},
@@ -658,21 +880,34 @@ def main():
                          "valu_floor_ms": valu_floor_ms,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": abytes,
                          # conservative companion: only the texel boxes the views actually touch
-                         "footprint_bytes_per_launch": fbytes, "frac_footprint": round(fbytes / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "e2e_render_ms": round(e2e_ms, 3), "e2e_render_max_ms": round(e2e_max_ms, 3), "e2e_render_back_to_back_ms": round(e2e_b2b_ms, 3),
-            "e2e_render_prefetched_poses_ms": round(e2e_pre_ms, 3), "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+                         "footprint_bytes_per_launch": fbytes, "frac_footprint": round(fbytes / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         # what a user of the pose distribution sees: the same bytes over the MEAN launch time of the `pose_sweep` draws
+                         "frac_pose_mean": None if not sweep else round(abytes / (sweep["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "pose_sweep": sweep, "numa_pin": pinned,
         }
+        if e2e is not None:
+            line.update({"e2e_render_ms": round(e2e["mean"], 3), "e2e_render_max_ms": round(e2e["max"], 3),
+                         "e2e_render_back_to_back_lagged_ms": round(e2e["b2b"], 3), "e2e_render_prefetched_poses_ms": round(e2e["pre"], 3)})
+        if use_dist:
+            # the only collective of the job, and the spread of the ranks (the headline time is the max over ranks)
+            line["rccl"] = {"world": dist.get_world_size(), "backend": dist.get_backend(), "gather_ms": round(gather_ms, 3),
+                            "gather_bytes": gather_bytes, "gather_gbs": round(gather_bytes / (gather_ms * 1e-3) / 1e9, 2),
+                            "what": "one all_gather_into_tensor of the finished frames [world, views, channels, H, W] fp32, second call (the first sets the communicator up)"}
+            line["ms_per_step_ranks"] = {"min": round(min(per_rank), 4), "max": round(max(per_rank), 4), "all": [round(x, 4) for x in per_rank]}
         if dry:
             line["dry_run"] = {"launches_on_rank0": dry_lib.launches, "gathered_shape": None if not use_dist else list(buf.shape)}
         if not a.no_parity:
-            line["parity"] = parity_block(r, rgba, dhw, ray, eye, zd, vpm, want_T, S)
+            line["parity"] = w.parity()
+        if not a.no_companions and world == 1 and a.workload == "cfg3" and not a.strict:
+            line["companions"] = companion_lines(a, dev, a.workload)
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(preset, S, D, dtype, a.cpu_budget)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
         parity_failed = bool(line.get("parity")) and not line["parity"]["ok"]
+        parity_failed = parity_failed or any(c.get("parity_ok") is False for c in (line.get("companions") or {}).values())
     else:
         parity_failed = False
     if use_dist:

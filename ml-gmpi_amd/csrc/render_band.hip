@@ -608,11 +608,10 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
         uint32_t rhh_c, gp_c;
         uint32_t g_off = 0;  // this lane's loader offset: a vector register through the plane loop (round 3 re-read it from LDS behind every barrier)
 #ifdef GMPI_PROF  // (the phase stamps wait for lgkmcnt(0): they would serialise the pipeline they are meant to time)
-        constexpr bool piped = false, piped32 = false, pipedG = false;
+        constexpr bool piped = false, pipedG = false;
 #else
         constexpr bool piped = BF && !STRICT && PPT == 2 && kNP == 3;
-        constexpr bool piped32 = !BF && !STRICT && PPT == 1 && kNP == 3;
-        constexpr bool pipedG = !STRICT && kNP == 5;   // the experiment geometries (twice the pixels per thread, half the waves): the same pipeline, written once for any PPT
+        constexpr bool pipedG = !STRICT && !piped;     // every other default-mode geometry (fp32 volumes as shipped: 2 pixels per thread, 5 DMA passes; any GMPI_BAND_PPT*): the same pipeline, written once for any pixel count
 #endif
         auto stage = [&](int tt, auto ub) {  // plane tt, held by buffer U
             constexpr int U = decltype(ub)::value;
@@ -707,43 +706,6 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                     smp[2] = bilerp<false>(tapf(tb[0]), tapf(tb[1]), tapf(tb[2]), tapf(tb[3]), f);
                     smp[3] = bilerp<false>(tapf(tb[4]), tapf(tb[5]), tapf(tb[6]), tapf(tb[7]), f);
                     blend<false>(A[1], smp[0], smp[1], smp[2], smp[3], p1.s, dots[1]);
-                }
-            } else if constexpr (piped32) {
-                // fp32 volumes (one pixel per thread): c (2 x b128) | b0 (channels R G: 4 x ds_read2_b32) | b1 (B A)
-                if (abl_nocomp) {
-                    if (check_range) {
-                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                        check_fold(cq0), check_fold(cq1);
-                        check_tail();
-                    }
-                } else {
-                    u32x2_t va[4], vb[4];
-                    Coords p0;
-                    Footprint f;
-                    float smp[4];
-                    if (check_range) {
-                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-                                     : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                    }
-                    coords(0, rf, rg, p0);
-                    const uint32_t a_bot = p0.a_tap + kRowBytes;
-                    taps32_issue(ic<0>{}, p0.a_tap, a_bot, va);                               // b0
-                    if (check_range) {
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(cq0), "+v"(cq1) : "i"(4));  // c has landed (b0 may still fly)
-                        check_fold(cq0), check_fold(cq1);
-                        check_tail();
-                    }
-                    taps32_issue(ic<1>{}, p0.a_tap, a_bot, vb);                               // b1
-                    taps32_land(ic<4>{}, va);
-                    f.nw = p0.nw, f.ne = p0.ne, f.sw = p0.sw, f.se = p0.se;
-                    smp[0] = bilerp<false>(__uint_as_float(va[0].x), __uint_as_float(va[0].y), __uint_as_float(va[1].x), __uint_as_float(va[1].y), f);
-                    smp[1] = bilerp<false>(__uint_as_float(va[2].x), __uint_as_float(va[2].y), __uint_as_float(va[3].x), __uint_as_float(va[3].y), f);
-                    asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));
-                    taps32_land(ic<0>{}, vb);
-                    smp[2] = bilerp<false>(__uint_as_float(vb[0].x), __uint_as_float(vb[0].y), __uint_as_float(vb[1].x), __uint_as_float(vb[1].y), f);
-                    smp[3] = bilerp<false>(__uint_as_float(vb[2].x), __uint_as_float(vb[2].y), __uint_as_float(vb[3].x), __uint_as_float(vb[3].y), f);
-                    blend<false>(A[0], smp[0], smp[1], smp[2], smp[3], p0.s, dots[0]);
                 }
             } else if constexpr (pipedG) {
                 // any PPT: c | A0 B0 | A1 B1 | ... (A = channels R G of a pixel, B = B A); every wait but the last leaves one batch in flight

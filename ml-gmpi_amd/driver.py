@@ -206,8 +206,12 @@ class ViewBatchDriver:
     def render_seeds(self, mpi_rgbas: torch.Tensor, render_size: int, views_per_mpi: int = 1, **render_kwargs):
         """Random-pose renders of a stack of MPIs [B,D,4,Ht,Wt] (prepare_fake_data.py:58-66 /
         fid_evaluation.py:116 pattern), `batch` MPIs per launch.  Returns the renderer's 4-tuple, concatenated."""
+        from .hip_mpi import flush_status
         outs = []
+        render_kwargs.setdefault("defer_status", "lag")   # (no frame leaves this method before every launch's assertions have been looked at)
         for s in range(0, mpi_rgbas.shape[0], self.batch):
             outs.append(self.renderer.render(mpi_rgbas[s:s + self.batch], render_size, render_size,
                                              views_per_mpi=views_per_mpi, **render_kwargs))
+        if render_kwargs["defer_status"] == "lag":
+            flush_status()
         return tuple(torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0])))

@@ -61,7 +61,7 @@ class MPIRenderer:
                  use_confined_volume=False, device=torch.device("cpu"),
                  # extensions (keyword-only, defaults = reference behaviour)
                  kernel_variant="auto", strict_order=False, range_check=None, on_out_of_plane="exit",
-                 ray_backend="auto", status_mode="lag"):
+                 ray_backend="auto", status_mode="sync"):
         self.mpi = MPI(align_corners=mpi_align_corners, variant=kernel_variant, strict_order=strict_order,
                        range_check=range_check, on_out_of_plane=on_out_of_plane)
         self.use_confined_volume = use_confined_volume
@@ -88,6 +88,9 @@ class MPIRenderer:
         if ray_backend == "auto":
             ray_backend = "hip" if torch.device(device).type == "cuda" else "torch"
         self.ray_backend = ray_backend
+        # "sync" (default): the assertions of a render fire in the call that trips them, as the reference's do (mpi.py:105-128, 185-187;
+        # mpi_renderer.py:447-449) -- one status read-back per call.  "lag" (opt-in: loops that never look at a frame before the next call, e.g.
+        # ViewBatchDriver.render_seeds): the read-back travels behind the kernel and a later call / flush_status() / exit raises (hip_mpi._StatusRing).
         assert status_mode in ("lag", "sync"), status_mode
         self.status_mode = "lag" if status_mode == "lag" else False
         self._batched_cam = None
@@ -403,9 +406,9 @@ class MPIRenderer:
         """(rgb [B,3,H,W] in [-1,1], depth [B,1,H,W], c2w [B,4,4], angles [B,2] = (pitch, yaw)) -- mpi_renderer.py:387-469.
 
         Extensions (keyword, optional): `want_transmittance=True` appends T [B,1,H,W] to the tuple;
-        `defer_status`: "lag" (the default, `status_mode` of the constructor) -- the asserts of this call are looked at by a later call,
-        by `ml_gmpi_amd.flush_status()` or at exit, without blocking the host on the kernel; False -- read back at once (the reference's
-        timing of the AssertionError); True -- not at all;
+        `defer_status`: False (the default, `status_mode="sync"` of the constructor) -- read back at once (the reference's timing of the
+        AssertionError); "lag" -- the asserts of this call are looked at by a later call, by `ml_gmpi_amd.flush_status()` or at exit, without
+        blocking the host on the kernel; True -- not at all;
         `views_per_mpi=k` renders k consecutive views per MPI without replicating the volume
         (the reference's n_view_per_z expand, prepare_fake_data.py:58-63, batch = B*k views).
         """
@@ -415,7 +418,7 @@ class MPIRenderer:
         vertical_std = self.vertical_std if vertical_std is None else vertical_std
         views_per_mpi = int(ext.pop("views_per_mpi", 1))
         want_T = bool(ext.pop("want_transmittance", False))
-        defer = ext.pop("defer_status", self.status_mode)   # "lag" (default) | False (read back at once) | True (the caller's status tensor / no check)
+        defer = ext.pop("defer_status", self.status_mode)   # False (default: read back at once) | "lag" | True (the caller's status tensor / no check)
         assert not ext, f"unknown arguments {list(ext)}"
 
         n_mpis = batch_mpi_rgbas.shape[0]
@@ -431,8 +434,10 @@ class MPIRenderer:
             frontal, tilted = self._frontal, self._tilted   # (known on the host: the poses were drawn here)
             # (the renderer's own ray buffers only when no autograd graph will hold them: `_RenderFunction` saves the camera tensors for its
             #  backward, and the next render() of this shape would overwrite them through a raw pointer -- no version counter sees that)
+            # (nor when the status check lags: the pending entry of this call keeps its camera tensors for the diagnostics of a tripped
+            #  assertion -- "pos / dir / min val" of THIS call, printed one or more calls later -- so a later call must not overwrite them)
             recording = torch.is_grad_enabled() and batch_mpi_rgbas.requires_grad
-            ray_t, eye_t, zd_t = self._generate_rays_hip(c2w, reuse=not recording)
+            ray_t, eye_t, zd_t = self._generate_rays_hip(c2w, reuse=not recording and defer != "lag")
         else:
             if given_cam_infos is None:
                 yaws, pitches, c2w, rays, eyes, zdirs = self.sample_cam_poses(

@@ -43,6 +43,15 @@ def test_bench_rank_logic_at_world_8(workload, views, chan):
     assert line["dry_run"]["gathered_shape"] == [world, views, chan, 32, 32]
     assert line["dry_run"]["launches_on_rank0"] >= line["steps"] + line["warmup"]
     assert line["gather_ms"] is not None and line["cpu_baseline"] is None
+    # round 5: what an N > 1 line says about its one collective and about stragglers (the headline clock is the max over ranks)
+    rc = line["rccl"]
+    assert rc["world"] == world and rc["backend"] == "gloo" and rc["gather_ms"] > 0 and rc["gather_gbs"] > 0
+    assert rc["gather_bytes"] == world * views * chan * 32 * 32 * 4
+    spread = line["ms_per_step_ranks"]
+    assert len(spread["all"]) == world and spread["min"] <= spread["max"] <= line["ms_per_step"] * 1.0001 + 1e-3
+    assert line["config"]["views_total"] == views * world
+    if workload in ("cfg4", "cfg5"):   # the BASELINE 8-GPU configurations, named in the line
+        assert "BASELINE configs" in line["config"]["workload"] and f"{views * world} views on {world} GPU" in line["config"]["workload"]
 
 
 def test_bench_single_process_dry_run():
@@ -51,3 +60,4 @@ def test_bench_single_process_dry_run():
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
     assert line["n_gpus"] == 1 and line["gather_ms"] is None and line["dry_run"]["gathered_shape"] is None
+    assert "rccl" not in line and "ms_per_step_ranks" not in line and line["roofline"]["frac_pose_mean"] is None

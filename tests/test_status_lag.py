@@ -1,6 +1,7 @@
-"""`MPIRenderer.render` looks at the status bits of a call one or a few calls late (hip_mpi._StatusRing): the host never blocks on the render
-kernel, and every assertion of the reference (mpi.py:70-72, 103-128, 185-187; mpi_renderer.py:447-449) still surfaces -- at a later call on
-the stream, at `flush_status()`, or at interpreter exit -- with the diagnostics of the call that tripped it."""
+"""`MPIRenderer.render` asserts in the call that trips the assertion by default (`status_mode="sync"`: the reference's timing, mpi.py:70-72,
+103-128, 185-187; mpi_renderer.py:447-449).  With `status_mode="lag"` / `defer_status="lag"` (opt-in) it looks at the status bits of a call one
+or a few calls late (hip_mpi._StatusRing): the host never blocks on the render kernel, and every assertion still surfaces -- at a later call on
+the stream, at `flush_status()`, or at interpreter exit (exit status 1) -- with the diagnostics of the call that tripped it."""
 import pytest
 import torch
 
@@ -10,6 +11,7 @@ pytestmark = pytest.mark.gpu
 def _setup(D=6, S=64, B=2, **kw):
     import ml_gmpi_amd
     dev = torch.device("cuda:0")
+    kw.setdefault("status_mode", "lag")   # (what this file is about; the default is "sync")
     r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=D, device=dev, on_out_of_plane="raise", **kw)
     rgba = torch.rand((B, D, 4, S, S), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
     return ml_gmpi_amd, r, rgba, S
@@ -103,3 +105,74 @@ def test_per_stream_state_is_bounded_and_thread_safe():
         t.join()
     m.flush_status()
     assert not errors, errors[:3]
+
+
+def test_default_is_the_reference_timing_also_through_install():
+    """The default renderer -- and the classes install() hands to the reference's scripts -- raise in the call that trips the assertion."""
+    import ml_gmpi_amd
+    from ml_gmpi_amd import install as inst
+    dev = torch.device("cuda:0")
+    D, S = 6, 64
+    rgba = torch.rand((2, D, 4, S, S), device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    bad = rgba.clone()
+    bad[1, 2, 3] = 1.5
+    kw = dict(ml_gmpi_amd.PRESETS["FFHQ"])
+    kw.update(n_mpi_planes=D, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse", cam_sample_method="truncated_gaussian",
+              mpi_align_corners=True, use_confined_volume=True, device=dev)
+    for cls in (ml_gmpi_amd.MPIRenderer, inst._installed_classes("full")[1], inst._installed_classes("touched")[1]):
+        r = cls(**kw)
+        assert r.status_mode is False
+        with torch.no_grad():
+            r.render(rgba, S, S)
+            with pytest.raises(AssertionError, match="alpha to be within"):
+                r.render(bad, S, S)
+            r.render(rgba, S, S)     # nothing left behind
+    ml_gmpi_amd.flush_status()
+
+
+def test_lagged_out_of_plane_reports_the_call_that_tripped_it(capsys):
+    """A tripped assert_not_out_of_last_plane in call n, then a DIFFERENT pose in call n + 1 (same shapes: the renderer's reused ray buffers
+    would have been overwritten): the message and the pos / dir print-out are call n's (mpi.py:105-128)."""
+    import re
+    m, r, rgba, S = _setup(D=4, S=64, B=1)
+    m.flush_status()
+    with torch.no_grad():
+        # a pose far outside the range the planes were sized for: rays leave the last plane
+        r.render(rgba, S, S, given_yaws=torch.full((1, 1), 1.2), given_pitches=torch.zeros(1, 1), random_pose=False)
+        torch.cuda.synchronize()
+        ref_r = m.make_renderer("FFHQ", n_planes=4, device=rgba.device, on_out_of_plane="raise", status_mode="sync")
+        with pytest.raises(RuntimeError) as sync_err:
+            ref_r.render(rgba, S, S, given_yaws=torch.full((1, 1), 1.2), given_pitches=torch.zeros(1, 1), random_pose=False)
+        sync_out = capsys.readouterr().out
+        with pytest.raises(RuntimeError) as lag_err:
+            r.render(rgba, S, S, given_yaws=torch.zeros(1, 1), given_pitches=torch.zeros(1, 1), random_pose=False)   # frontal: in range by itself
+            m.flush_status()
+        lag_out = capsys.readouterr().out
+    assert str(lag_err.value) == str(sync_err.value), (str(lag_err.value), str(sync_err.value))
+    assert re.search(r"goes out of plane at .*(min|max) val", str(lag_err.value))
+    pos = lambda t: t[t.index("pos:"):t.index("yaws:")] if "yaws:" in t else t[t.index("pos:"):]   # noqa: E731
+    assert pos(lag_out) == pos(sync_out)          # the tilted call's eye position and corner ray, not the frontal call's
+    m.flush_status()
+
+
+def test_lagged_assertion_at_exit_is_exit_status_1(tmp_path):
+    """Python ignores exceptions raised by atexit handlers (exit status 0): the handler reports and leaves with status 1 instead."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import ml_gmpi_amd\n"
+        "dev = torch.device('cuda:0')\n"
+        "r = ml_gmpi_amd.make_renderer('FFHQ', n_planes=4, device=dev, on_out_of_plane='raise', status_mode='lag')\n"
+        "rgba = torch.rand((1, 4, 4, 64, 64), device=dev)\n"
+        "rgba[0, 1, 3] = 2.0\n"
+        "with torch.no_grad():\n"
+        "    r.render(rgba, 64, 64)\n"
+        "print('script end')\n")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "script end" in res.stdout
+    assert res.returncode == 1, (res.returncode, res.stderr[-500:])
+    assert "alpha to be within" in res.stderr
