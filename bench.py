@@ -610,8 +610,8 @@ class Workload:
 def companion_lines(a, dev, main_name):
     """Rank 0, N = 1, OUTSIDE the timed region: the configurations that otherwise have no driver-run witness -- config 3 with an fp32 volume (the
     1024^2 x 96 variant whose kernel is memory-side bound), config 2 (BASELINE configs[1]), and config 3 in strict-order mode (the bit-identical
-    arithmetic the parity tests run).  Each: its own tensors, 5 warm-up + 20 launches with a HIP-event pair around every launch on the launch
-    stream (the GPU is at its busy clocks: the timed steps have just run), mean of the 20; frac = algorithmic bytes / mean / 8 TB/s; and the same
+    arithmetic the parity tests run).  Each: its own tensors, the same untimed clock ramp as the headline (--prewarm-ms), 5 warm-up + 20 launches
+    with a HIP-event pair around every launch on the launch stream, mean of the 20; frac = algorithmic bytes / mean / 8 TB/s; and the same
     oracle comparison as the headline's `parity` block.  Not `value`; a witness."""
     res = {}
     for key, name, strict in (("cfg3_f32", "cfg3_f32", False), ("cfg2", "cfg2", False), ("cfg3_strict", "cfg3", True)):
@@ -620,6 +620,13 @@ def companion_lines(a, dev, main_name):
         try:
             w = Workload(name, dev, variant=a.variant, strict=strict)
             with torch.no_grad():
+                # (the oracle comparison of the block before this one ran on the host for seconds: the GPU's clocks have dropped -- the same
+                #  untimed ramp as in front of the headline's warm-up steps)
+                t_pre = time.perf_counter()
+                while (time.perf_counter() - t_pre) * 1e3 < a.prewarm_ms:
+                    for _ in range(8):
+                        w.step()
+                    torch.cuda.synchronize(dev)
                 for _ in range(5):
                     w.step()
                 evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]

@@ -1,76 +1,60 @@
-"""Backward of the fused render at the reference's training sizes (gmpi.yml:78 D=32; curriculums.py:91-93 batch 8/4/4
-at 256/512/1024): HIP events around forward and forward+backward through torch autograd (incl. the zero fill of the
-gradient volume), for the tile-staged scatter (default) and the one-pixel-per-lane kernel (variant "gather").
-usage: python tools/time_backward.py"""
+"""Times the backward launch (and the forward) at the G-step shapes through the C ABI.  usage: python tools/time_backward.py [lib.so]
+(GMPI_TUNE_SKIP in the environment selects ablations of a profiling build: 16 no global atomics in the flush, 32 no LDS atomics, 64 the
+round-1 tile kernel, 128 no tap loads.)"""
+import ctypes
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import ml_gmpi_amd  # noqa: E402
+from ml_gmpi_amd import _lib  # noqa: E402
 
+if len(sys.argv) > 1:
+    _lib._SO = os.path.abspath(sys.argv[1])
+    _lib._LIB = None
+lib = _lib.load_library()
+print("library:", _lib._SO, flush=True)
 dev = torch.device("cuda:0")
-
-
-def timeit(fn, n=10):
-    fn(); fn()
-    torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(n):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / n
-
-
-for S, B in ((256, 8), (512, 4), (1024, 4)):
-    D = 32
-    for variant in ("auto", "gather"):
-        r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=D, device=dev, on_out_of_plane="raise", kernel_variant=variant)
-        vol = torch.rand((B, D, 4, S, S), device=dev)
-        vol[:, -1, 3] = 1.0
-        vol.requires_grad_(True)
-        torch.manual_seed(0)
-        r.set_cam(r.cam_fov, S, S)
-        cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
-        infos = dict(zip(["batch_yaws", "batch_pitches", "batch_tf_c2w", "batch_ray_dir", "batch_eye_pos", "batch_z_dir"], cam))
-        g = torch.randn((B, 3, S, S), device=dev)
-
-        def fwd():
-            with torch.no_grad():
-                return r.render(vol.detach(), S, S, given_cam_infos=infos, defer_status=True)
-
-        def fwdbwd():
-            vol.grad = None
-            rgb = r.render(vol, S, S, given_cam_infos=infos, defer_status=True)[0]
-            (rgb * g).sum().backward()
-
-        tf, tfb = timeit(fwd), timeit(fwdbwd)
-        print(f"{S}^2 x {D} planes, batch {B}, variant {variant:6s}: forward {tf:.3f} ms, forward+backward {tfb:.3f} ms "
-              f"(backward ~{tfb - tf:.3f} ms = {B * S * S * D / (tfb - tf) / 1e3:.0f} Mpix*planes/s)")
-
-# ---- the shading augmentation in front of it (train.py:535-541): LightRenderer.render forward and forward+backward ----
 for S, B in ((256, 8), (512, 4), (1024, 4)):
     D = 32
     r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=D, device=dev, on_out_of_plane="raise")
-    L = ml_gmpi_amd.LightRenderer(sphere_center_z=1.0, sphere_r=1.0, ka_max=0.9, kd_max=0.1, n_grow_iters=1)
-    L.step = 10
-    vol = torch.rand((B, D, 4, S, S), device=dev)
+    r.set_cam(r.cam_fov, S, S)
+    g = torch.Generator(device=dev).manual_seed(7000)
+    vol = torch.rand((B, D, 4, S, S), device=dev, generator=g)
     vol[:, -1, 3] = 1.0
-    vol.requires_grad_(True)
-    xyz, _ = r.get_xyz(S, S, ret_single_res=True)
-    g = torch.randn((B, D, 4, S, S), device=dev)
+    gc = torch.randn((B, 3, S, S), device=dev, generator=g)
+    gd = torch.randn((B, 1, S, S), device=dev, generator=g)
+    torch.manual_seed(3)
+    cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+    ray, eye, zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+    dhw = r._dhw_on_device().expand(B, -1, -1).contiguous()
+    res = r.mpi.render_views(vol, dhw, ray, eye, zd, views_per_mpi=1, check_last_plane=True, out_pm1=True, want_transmittance=True,
+                             defer_status=True, _in_autograd_fn=True)
+    p, keep = res["_bwd"]
+    p.rgb_out = p.depth_out = None
+    prof = torch.zeros(64, dtype=torch.int32, device=dev)
+    p.status = prof.data_ptr() if os.environ.get("GMPI_PROF_WORDS") else None
+    grad = torch.zeros_like(vol)
+    gs = (ctypes.c_int64 * 5)(*grad.stride())
+    cs = torch.cuda.current_stream(dev).cuda_stream
 
-    def lfwd():
-        with torch.no_grad():
-            return L.render(vol.detach(), r.static_mpi_plane_dhws, xyz)
-
-    def lfwdbwd():
-        vol.grad = None
-        (L.render(vol, r.static_mpi_plane_dhws, xyz) * g).sum().backward()
-
-    tf, tfb = timeit(lfwd), timeit(lfwdbwd)
-    gb = B * D * S * S * 16 / 1e9
-    print(f"LightRenderer {S}^2 x {D} planes, batch {B}: forward {tf:.3f} ms, forward+backward {tfb:.3f} ms (volume {gb:.2f} GB fp32)")
+    def bwd():
+        _lib.check(lib.gmpi_mpi_render_backward_launch(ctypes.byref(p), gc.data_ptr(), gd.data_ptr(), grad.data_ptr(), gs, cs), "bwd")
+    import time
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:   # clock ramp
+        for _ in range(8):
+            bwd()
+        torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for e0, e1 in evs:
+        e0.record(); bwd(); e1.record()
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+    print(f"backward {S}^2 x {D} x {B}: {ms:.4f} ms  (skip={os.environ.get('GMPI_TUNE_SKIP', '0')})", flush=True)
+    if os.environ.get("GMPI_PROF_WORDS"):   # a -DGMPI_PROF build: shader-clock cycles of one pixel wave | one flush wave over the whole tile
+        w = prof.cpu().tolist()
+        print(f"   pixel wave: scatter {w[8]} grads {w[9]} fetch {w[10]} barrier {w[11]} prologue {w[13]} total {w[14]} | flush wave: flush {w[16]} barrier {w[19]} prologue {w[21]} total {w[22]}")
