@@ -377,7 +377,15 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
     const bool flusher = __builtin_amdgcn_readfirstlane(tid) >= kB2Pix;
     const int ptid = flusher ? 0 : tid, ftid = tid - kB2Pix;
     const int n = blockIdx.y;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+    // XCD x = blockIdx.x % 8 (workgroups are dealt round-robin to the 8 XCDs) takes a contiguous, row-major run of the view's tiles: neighbours
+    // share the halo rows of their boxes -- the taps they read and the gradient lines they add into -- in one L2 / from one XCD
+    const int n_tiles = tiles_x * ((p.H + kB2TH - 1) / kB2TH);
+    int tile = xcd_item_per_group(static_cast<int>(blockIdx.x), n_tiles, n_tiles);
+#ifdef GMPI_TUNE
+    if (p.flags & (1u << 24)) tile = blockIdx.x < static_cast<unsigned>(n_tiles) ? static_cast<int>(blockIdx.x) : n_tiles;   // GMPI_TUNE_SKIP=256: row-major order as dealt
+#endif
+    if (tile >= n_tiles) return;   // (whole workgroup: the grid is padded to a multiple of 8)
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
     const int px = txi * kB2TW + (ptid % kB2TW), py = tyi * kB2TH + (ptid / kB2TW);
     const bool active = !flusher && px < p.W && py < p.H;
     uint32_t bad_index = 0;  // (the forward reports a bad view index; here it is only clamped)
@@ -704,6 +712,7 @@ static hipError_t launch_backward_t(const KParams& p, const BwdParams& b, bool t
     if (tiles) {
         const int tiles_x = (p.W + kBwdTW - 1) / kBwdTW, tiles_y = (p.H + kBwdTH - 1) / kBwdTH;
         const dim3 grid(tiles_x * tiles_y, p.N), block(kBwdThreads), block2(kB2Threads);
+        const dim3 grid2(xcd_grid_per_group(tiles_x * tiles_y, tiles_x * tiles_y), p.N);
         static_assert(kBwdTW == kB2TW && kBwdTH == kB2TH && kBwdThreads == kB2Pix, "one grid for both tile kernels");
         // the round-5 kernel wants two columns (pair loads) and a plane's offsets -- volume and gradient -- in 32 bits
         const int es = static_cast<int>(sizeof(TexT));
@@ -716,8 +725,8 @@ static hipError_t launch_backward_t(const KParams& p, const BwdParams& b, bool t
             if (ac) hipLaunchKernelGGL((render_backward_tile_kernel<TexT, true>), grid, block, 0, stream, p, b, tiles_x);
             else hipLaunchKernelGGL((render_backward_tile_kernel<TexT, false>), grid, block, 0, stream, p, b, tiles_x);
         } else {
-            if (ac) hipLaunchKernelGGL((render_backward_tile2_kernel<TexT, true>), grid, block2, 0, stream, p, b, tiles_x);
-            else hipLaunchKernelGGL((render_backward_tile2_kernel<TexT, false>), grid, block2, 0, stream, p, b, tiles_x);
+            if (ac) hipLaunchKernelGGL((render_backward_tile2_kernel<TexT, true>), grid2, block2, 0, stream, p, b, tiles_x);
+            else hipLaunchKernelGGL((render_backward_tile2_kernel<TexT, false>), grid2, block2, 0, stream, p, b, tiles_x);
         }
         return hipGetLastError();
     }
@@ -732,7 +741,7 @@ static hipError_t launch_backward_t(const KParams& p, const BwdParams& b, bool t
 hipError_t launch_backward(const KParams& p0, int dtype, const float* g_rgb, const float* g_depth, float* g_rgba,
                            const int64_t* gstride, bool tiles, hipStream_t stream) {
     KParams p = p0;
-#ifdef GMPI_TUNE  // profiling builds only: 16 = no global atomics in the flush, 32 = no LDS atomics, 64 = the round-1 tile kernel, 128 = no tap loads
+#ifdef GMPI_TUNE  // profiling builds only: 16 = no global atomics in the flush, 32 = no LDS atomics, 64 = the round-1 tile kernel, 128 = no tap loads, 256 = tiles in row-major order over the XCDs
     static const unsigned skip = [] { const char* e = getenv("GMPI_TUNE_SKIP"); return e ? static_cast<unsigned>(atoi(e)) : 0u; }();
     p.flags |= skip << 16;
 #endif

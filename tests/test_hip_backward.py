@@ -228,3 +228,84 @@ def test_inplace_update_between_forward_and_backward_is_detected():
     mpi.render_views(alone, t(dhw), t(ray), t(eye), t(zd), check_last_plane=False)["color"].sum().backward()
     assert torch.allclose(a.grad, alone.grad, rtol=1e-4, atol=1e-6)
     assert torch.equal(shared["T"], out_b["T"])
+
+
+def _rot_cam(N, H, W, yaw, pitch, roll, fov=0.11):
+    """Pinhole rays of N cameras on the unit sphere around (0, 0, 1), looking at it, with an in-plane roll: the tilt and the rotation
+    shear the texel boxes of neighbouring tiles against each other."""
+    ys, xs = np.meshgrid(np.linspace(-fov, fov, H), np.linspace(-fov, fov, W), indexing="ij")
+    rays, eyes, zds = [], [], []
+    for n in range(N):
+        sgn = 1 if n % 2 == 0 else -1
+        a, b, c = sgn * yaw, (0.5 + 0.5 * n / max(N - 1, 1)) * pitch, sgn * roll
+        Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        Rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+        R = Ry @ Rx @ Rz
+        d = np.stack([xs, ys, np.ones_like(xs)]).reshape(3, -1)
+        d = d / np.linalg.norm(d, axis=0)
+        rays.append((R @ d).reshape(3, H, W))
+        eyes.append(np.array([0.0, 0.0, 1.0]) - R[:, 2])
+        zds.append(R[:, 2])
+    return (np.stack(rays).astype(np.float32), np.array(eyes, np.float32), np.array(zds, np.float32))
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(H=160, W=160, Ht=128, Wt=128, yaw=0.0, pitch=0.0, roll=0.0),      # frontal: 5 x 10 tiles, interior tiles with a whole 5 x 5 block
+    dict(H=160, W=192, Ht=192, Wt=160, yaw=0.35, pitch=0.12, roll=0.0),    # tilted: sheared boxes
+    dict(H=144, W=160, Ht=128, Wt=128, yaw=0.25, pitch=-0.1, roll=0.5),    # in-plane rotation: neighbours' boxes overlap on two sides
+    dict(H=144, W=160, Ht=128, Wt=128, yaw=0.1, pitch=0.1, roll=1.3),      # nearly a quarter turn: "left" tiles lie above
+    dict(H=96, W=224, Ht=40, Wt=56, yaw=0.3, pitch=0.0, roll=0.2),         # texture coarser than the image: tiles several columns apart share texels
+    dict(H=100, W=130, Ht=300, Wt=260, yaw=0.3, pitch=0.1, roll=-0.3),     # texture finer than the image: large boxes (some not staged)
+])
+def test_tile_backward_matches_the_all_atomic_kernel(cfg):
+    """The round-5 tile backward (pipelined planes, fixed-point boxes, flush waves) on many tiles under tilted and ROTATED cameras -- sheared boxes,
+    neighbours that overlap on two sides, textures coarser and finer than the image -- against the one-pixel-per-lane kernel (GMPI_VARIANT_GATHER:
+    16 global atomics per pixel and plane, no staging) and against float64 autograd of the same forward.  (Written for round 5's exclusive-cell
+    experiment -- plain stores for box cells no other tile touches; correct, slower, not kept: profiles/r05_backward.txt -- and kept as the
+    multi-tile cross-check the backward did not have.)"""
+    from ml_gmpi_amd import MPI
+    N = M = 2
+    D = 5
+    H, W, Ht, Wt = cfg["H"], cfg["W"], cfg["Ht"], cfg["Wt"]
+    rgba = oracle.synth_rgba(61, (M, D, 4, Ht, Wt))
+    ray, eye, zd = _rot_cam(N, H, W, cfg["yaw"], cfg["pitch"], cfg["roll"])
+    dhw = _dhw(M, D, ext=0.30, last=0.6)
+    v2m = np.arange(N)
+    g = np.random.default_rng(9)
+    gc = g.standard_normal((N, 3, H, W)).astype(np.float32)
+    gd = g.standard_normal((N, 1, H, W)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    grads = {}
+    for variant in ("auto", "gather"):
+        vol = t(rgba).requires_grad_(True)
+        mpi = MPI(align_corners=True, variant=variant, on_out_of_plane="raise")
+        out = mpi.render_views(vol, t(dhw), t(ray), t(eye), t(zd), views_per_mpi=1, check_last_plane=False)
+        ((out["color"] * t(gc)).sum() + (out["depth"] * t(gd)).sum()).backward()
+        grads[variant] = vol.grad.cpu().numpy()
+    scale = np.abs(grads["gather"]).max()
+    assert scale > 0
+    assert np.abs(grads["auto"] - grads["gather"]).max() <= 1e-5 * scale, (np.abs(grads["auto"] - grads["gather"]).max(), scale)
+    # (float64 coordinates against fp32 ones on white noise, hundreds of pixels per row: a little looser than the small cases above)
+    _, _, ref_g = _ref_grads(rgba, dhw, ray, eye, zd, v2m, gc, gd, True)
+    assert np.abs(grads["auto"] - ref_g).max() <= 5e-5 * np.abs(ref_g).max() + 1e-6
+
+
+def test_tile_backward_several_views_per_mpi_keep_their_atomics():
+    """Two views of ONE MPI add into the same gradient volume."""
+    from ml_gmpi_amd import MPI
+    N, M, D, S = 4, 2, 4, 128
+    rgba = oracle.synth_rgba(62, (M, D, 4, S, S))
+    ray, eye, zd = _rot_cam(N, S, S, 0.2, 0.1, 0.1)
+    dhw = _dhw(M, D, ext=0.30, last=0.6)
+    g = np.random.default_rng(10)
+    gc = g.standard_normal((N, 3, S, S)).astype(np.float32)
+    gd = g.standard_normal((N, 1, S, S)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    vol = t(rgba).requires_grad_(True)
+    out = MPI(align_corners=True, on_out_of_plane="raise").render_views(vol, t(dhw), t(ray), t(eye), t(zd), views_per_mpi=2, check_last_plane=False)
+    ((out["color"] * t(gc)).sum() + (out["depth"] * t(gd)).sum()).backward()
+    _, _, ref_g = _ref_grads(rgba, dhw, ray, eye, zd, np.repeat(np.arange(M), 2), gc, gd, True)
+    assert np.abs(vol.grad.cpu().numpy() - ref_g).max() <= 2e-5 * np.abs(ref_g).max() + 1e-6
