@@ -210,7 +210,15 @@ __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const
     const int band_id = blockIdx.x;
     int n, brem;
     band_to_view(p, band_id, bands_x * bands_y, n, brem);
+    // band index inside the view -> (column, row) of bands, COLUMN-major (round 5): an XCD's contiguous run of bands walks DOWN a column of
+    // bands, so the workgroups that run next to each other in time and on one XCD are vertical neighbours -- they share 2-3 of their ~10 box
+    // rows, horizontal neighbours 2 of ~130 box columns.  Against the row-major order of rounds 3-4, same box, two alternating repeats: config 5
+    // 3.29 / 3.35 -> 3.19 / 3.16 ms, config 3 fp32 1.208 / 1.238 -> 1.197 / 1.211, bf16 0.848 / 0.857 -> 0.845 / 0.838 (profiles/r05_band_order.txt).
+#ifdef GMPI_BAND_ROWMAJOR
     const int byi = brem / bands_x, bxi = brem - byi * bands_x;
+#else
+    const int bxi = brem / bands_y, byi = brem - bxi * bands_y;
+#endif
     uint32_t ignore = 0;
     const int m = view_mpi(p, n, ignore);
     const int Ht = p.Ht, Wt = p.Wt, H = p.H, W = p.W;
@@ -295,8 +303,8 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kOffBytes)));
 
-    // ---- blockIdx -> band.  XCD x = blockIdx % 8 gets a contiguous run of the bands of EVERY view (group of views that share an MPI): row-major
-    //      neighbours share halo rows in one L2, and the XCDs walk the views together (measured 4 % faster than one run of all bands per XCD,
+    // ---- blockIdx -> band.  XCD x = blockIdx % 8 gets a contiguous run of the bands of EVERY view (group of views that share an MPI): neighbours
+    //      (column-major since round 5, see below) share halo rows in one L2, and the XCDs walk the views together (measured 4 % faster than one run of all bands per XCD,
     //      where different XCDs read different views at the same time) ----
     int band_id = xcd_item_per_group(blockIdx.x, bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands);
 #ifdef GMPI_TUNE  // (experiment: one contiguous run of ALL bands per XCD)
@@ -306,7 +314,15 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     int n, brem;
     band_to_view(p, band_id, bands_x * bands_y, n, brem);
     if (view_gated_out(p, n)) return;  // (AUTO: a view with a box that does not fit is the tile kernel's)
+    // band index inside the view -> (column, row) of bands, COLUMN-major (round 5): an XCD's contiguous run of bands walks DOWN a column of
+    // bands, so the workgroups that run next to each other in time and on one XCD are vertical neighbours -- they share 2-3 of their ~10 box
+    // rows, horizontal neighbours 2 of ~130 box columns.  Against the row-major order of rounds 3-4, same box, two alternating repeats: config 5
+    // 3.29 / 3.35 -> 3.19 / 3.16 ms, config 3 fp32 1.208 / 1.238 -> 1.197 / 1.211, bf16 0.848 / 0.857 -> 0.845 / 0.838 (profiles/r05_band_order.txt).
+#ifdef GMPI_BAND_ROWMAJOR
     const int byi = brem / bands_x, bxi = brem - byi * bands_x;
+#else
+    const int bxi = brem / bands_y, byi = brem - bxi * bands_y;
+#endif
 
     const int tid = threadIdx.x;
     // Registers are the scarce resource (64 per lane for 8 waves per SIMD): values that only depend on the thread index are
