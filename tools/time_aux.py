@@ -31,26 +31,7 @@ ms = timeit(lambda: ml_gmpi_amd.frames_to_uint8(rgb, dep, 0.95, 1.12))
 print(f"frames_to_uint8 8 frames 1024^2: {ms:.3f} ms")
 
 # ---- backward at the reference's training sizes (gmpi.yml:78 D=32; curriculums.py:91-93 batch 8/4/4 @ 256/512/1024) ----
-for S, B in ((256, 8), (512, 4), (1024, 4)):
-    D = 32
-    r = ml_gmpi_amd.make_renderer("FFHQ", n_planes=D, device=dev, on_out_of_plane="raise")
-    vol = torch.rand((B, D, 4, S, S), device=dev); vol[:, -1, 3] = 1.0
-    vol.requires_grad_(True)
-    torch.manual_seed(0)
-    r.set_cam(r.cam_fov, S, S)
-    cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
-    infos = dict(zip(["batch_yaws", "batch_pitches", "batch_tf_c2w", "batch_ray_dir", "batch_eye_pos", "batch_z_dir"], cam))
-    g = torch.randn((B, 3, S, S), device=dev)
-    def fwd():
-        with torch.no_grad():
-            return r.render(vol.detach(), S, S, given_cam_infos=infos, defer_status=True)
-    def fwdbwd():
-        vol.grad = None
-        rgb = r.render(vol, S, S, given_cam_infos=infos, defer_status=True)[0]
-        (rgb * g).sum().backward()
-    tf, tfb = timeit(fwd, 10), timeit(fwdbwd, 10)
-    print(f"train-size {S}^2 x {D} planes, batch {B}: forward {tf:.3f} ms, forward+backward {tfb:.3f} ms "
-          f"(backward ~{tfb - tf:.3f} ms, {B*S*S*D*16/ (tfb-tf)/1e6:.1f} G atomics/s)")
+# (the G-step shapes -- forward + backward -- are bench.py --workload train256 / train512 / train1024 since round 5)
 
 # ---- shading augmentation (LightRenderer.render) on a 4 x 96 x 1024^2 volume, kernel by kernel ----
 import ctypes
