@@ -318,8 +318,8 @@ __global__ __launch_bounds__(kBwdThreads, 6) void render_backward_tile_kernel(co
 //     address space: on this part it drains vmcnt, i.e. every plane would wait for its own prefetch and for the flush's global atomics;
 //   * two boxes fit because the staged sums are 32-bit fixed point (v_cvt_i32_f32 + ds_add_u32 instead of a double conversion +
 //     ds_add_u64): per plane and tile the largest |sample gradient| M is scaled to 2^(30 - h), h = the bits of headroom for the taps that
-//     can meet in one texel (from the pixel density of the tile on that plane: 5 bits at one pixel per texel, 11 = every tap of the tile
-//     when the texture is much coarser than the image), i.e. a resolution of <= 2^-25 M per add at one pixel per texel -- finer than
+//     can meet in one texel (from the pixel density of the tile on that plane: 4 bits at one pixel per texel, 11 = every tap of the tile
+//     when the texture is much coarser than the image), i.e. <= 2^-27 M per add (rounded to nearest) at one pixel per texel -- finer than
 //     the rounding of a chain of fp32 atomic adds (2^-24 of the running sum);
 //   * WAVE ROLES: vector loads, stores and atomics of a wave share one counter (vmcnt) and retire in order, so a wave that flushes (global
 //     atomics: a read-modify-write at L2 behind an HBM miss) and then gathers sits out its own atomics before it sees its taps.  The 8
@@ -344,6 +344,13 @@ template <> __device__ __forceinline__ void load_pair<float>(const unsigned char
     float v[2];
     __builtin_memcpy(v, base + byte_off, 8);  // (one global_load_dwordx2 at dword alignment, uniform base + 32-bit lane offset)
     a = v[0], b = v[1];
+}
+// round to nearest (floor(x + 0.5)) in one instruction: the staged sums must not be biased -- with a texture much coarser than the image a hundred
+// taps meet in one texel, and a truncating conversion adds up to half a unit of the fixed-point grid PER TAP in one direction
+__device__ __forceinline__ int cvt_rpi(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // Maximum of an unsigned word over the 64 lanes of a wave (EVERY lane must be enabled), as a scalar: four row shifts and two row broadcasts on
@@ -519,22 +526,37 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
         const bool any_w = nw != 0.0f || ne != 0.0f || sw != 0.0f || se != 0.0f;
         if (staged && in_box && active) {
             // scale = 2^(29 - h - floor(log2 M)): |d * weight * scale| < 2^(30 - h), and at most 2^h taps meet in one word
-            const int hbits = __float_as_int(pcB[t].y);
-            const int shf = min(29 - hbits - (static_cast<int>(mb >> 23) - 127), 126);
+            const int hword = __float_as_int(pcB[t].y);
+            const int hbits = hword & 0xff;
+            const bool wide = (hword & 0x100) != 0;   // workgroup-uniform: two words per cell, |d * weight * scale| < 2^(42 - h)
+            const int shf = min((wide ? 41 : 29) - hbits - (static_cast<int>(mb >> 23) - 127), 126);
             const float sc = __builtin_amdgcn_ldexpf(1.0f, shf);
             const float fnw = nw * sc, fne = ne * sc, fsw = sw * sc, fse = se * sc;   // (a power of two: exact)
             uint32_t* __restrict__ l0 = bx_acc + ly * (4 * kB2Pitch) + lx;
-            if (!abl_nolds) {
+            if (wide && !abl_nolds) {
+                auto add2 = [&](uint32_t* __restrict__ cell, float v) {   // v = hi * 2^12 + lo exactly (fp32: 24 significant bits), hi rounded to nearest
+                    const int hi = cvt_rpi(v * (1.0f / 4096.0f));
+                    const int lo = cvt_rpi(__builtin_fmaf(-static_cast<float>(hi), 4096.0f, v));
+                    atomicAdd(cell, static_cast<uint32_t>(hi));
+                    atomicAdd(cell + kB2Cap / 2, static_cast<uint32_t>(lo));
+                };
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float d = gq.d[c4];
+                    uint32_t* __restrict__ lc = l0 + c4 * kB2Pitch;
+                    add2(lc, d * fnw), add2(lc + 1, d * fne), add2(lc + 4 * kB2Pitch, d * fsw), add2(lc + 4 * kB2Pitch + 1, d * fse);
+                }
+            } else if (!abl_nolds) {
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     const float d = gq.d[c4];
                     uint32_t* __restrict__ lc = l0 + c4 * kB2Pitch;
                     // (a tap outside the texture has weight 0 and adds 0 to a box cell outside the texture, which the flush never writes out;
-                    //  the conversion truncates: at most one unit of 2^-(30 - h) M per add)
-                    atomicAdd(lc, static_cast<uint32_t>(static_cast<int>(d * fnw)));
-                    atomicAdd(lc + 1, static_cast<uint32_t>(static_cast<int>(d * fne)));
-                    atomicAdd(lc + 4 * kB2Pitch, static_cast<uint32_t>(static_cast<int>(d * fsw)));
-                    atomicAdd(lc + 4 * kB2Pitch + 1, static_cast<uint32_t>(static_cast<int>(d * fse)));
+                    //  round to nearest: at most half a unit of 2^-(30 - h) M per add, in either direction)
+                    atomicAdd(lc, static_cast<uint32_t>(cvt_rpi(d * fnw)));
+                    atomicAdd(lc + 1, static_cast<uint32_t>(cvt_rpi(d * fne)));
+                    atomicAdd(lc + 4 * kB2Pitch, static_cast<uint32_t>(cvt_rpi(d * fsw)));
+                    atomicAdd(lc + 4 * kB2Pitch + 1, static_cast<uint32_t>(cvt_rpi(d * fse)));
                 }
             }
         }
@@ -567,14 +589,28 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
         const int4 bb = box[t];
         const uint32_t mb = gmax[t];
         if (!(bb.z > 0 && mb < 0x7f800000u && mb != 0u)) return;
-        const int hbits = __float_as_int(pcB[t].y);
-        const int shf = min(29 - hbits - (static_cast<int>(mb >> 23) - 127), 126);
+        const int hword = __float_as_int(pcB[t].y);
+        const int hbits = hword & 0xff;
+        const bool wide = __builtin_amdgcn_readfirstlane(hword & 0x100) != 0;
+        const int shf = min((wide ? 41 : 29) - hbits - (static_cast<int>(mb >> 23) - 127), 126);
         const float inv = __builtin_amdgcn_ldexpf(1.0f, -shf);
         const int nx = __builtin_amdgcn_readfirstlane(bb.z), nlines = __builtin_amdgcn_readfirstlane(bb.w) * 4;
         float* __restrict__ gp = gvol + static_cast<int64_t>(k) * b.gs_plane + static_cast<int64_t>(__builtin_amdgcn_readfirstlane(bb.y)) * b.gs_row +
                                  __builtin_amdgcn_readfirstlane(bb.x);
         const bool on = flane < nx;
         uint32_t* __restrict__ src0 = bx_acc + flane;
+        if (wide) {   // two words per cell (see the tables): value = hi * 2^12 + lo
+            for (int line = fw; line < nlines; line += kFW) {
+                if (!on) continue;
+                const int qh = static_cast<int>(src0[line * kB2Pitch]), ql = static_cast<int>(src0[line * kB2Pitch + kB2Cap / 2]);
+                if ((qh | ql) != 0) {
+                    src0[line * kB2Pitch] = 0u, src0[line * kB2Pitch + kB2Cap / 2] = 0u;
+                    const float v = __builtin_fmaf(static_cast<float>(qh), 4096.0f, static_cast<float>(ql)) * inv;
+                    if (!abl_noglobal) atomicAdd(gp + (static_cast<uint32_t>(line & 3) * gs_chan + static_cast<uint32_t>(line >> 2) * gs_row) + flane, v);
+                }
+            }
+            return;
+        }
         for (int l0 = fw; l0 < nlines; l0 += 4 * kFW) {
             int q[4];
 #pragma unroll
@@ -628,11 +664,20 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
                 bb.z = static_cast<int>(floorf(mxx + eps)) + 2 - bb.x, bb.w = static_cast<int>(floorf(mxy + eps)) + 2 - bb.y;
                 if (bb.z > kB2Pitch || bb.w > kB2Rows) bb.z = 0;
                 else {
-                    // taps that can meet in one texel: 4 x the tile's pixels per texel on average; 16 x + 16 is the bound used (a homography is
+                    // taps that can meet in one texel: 4 x the tile's pixels per texel on average; 8 x + 8 is the bound used (a homography is
                     // smooth over a 32 x 16 pixel tile), 2^11 = every tap of the tile when the box is only a few texels
                     const int area = max((bb.z - 1) * (bb.w - 1), 1);
-                    const int bound = (16 * npix + area - 1) / area + 16;
+                    const int bound = (8 * npix + area - 1) / area + 8;
                     hbits = min(11, 32 - __clz(bound - 1));
+#ifdef GMPI_B2_HBITS  // (experiment: a fixed headroom)
+                    hbits = GMPI_B2_HBITS;
+#endif
+                    // WIDE planes: with 9 and more bits of headroom (a texture several times coarser than the image: a hundred and more taps
+                    // per texel) one 32-bit word leaves less than 2^-21 of the tile's largest gradient per add -- the round-1 kernel's 64-bit sums
+                    // were measurably better there (tools/fuzz_backward_gpu.py: 1.2e-5 against 2.5e-6 of the largest gradient).  Such a box is
+                    // small: when its rows fill at most half of the buffer, every cell gets a second word (the residual of the first, 12 bits
+                    // finer) in the other half.
+                    if (hbits >= 9 && bb.w * 4 * kB2Pitch <= kB2Cap / 2) hbits |= 0x100;
                 }
             }
             box[t] = bb;
