@@ -53,9 +53,11 @@ enum {
                                             (the 2-sigma corner of the FFHQ / MetFaces pose range).  The strip kernel's wave-private boxes
                                             overflow there -- config 2 takes 0.25-0.77 ms instead of 0.16 -- while the tile kernel stays at
                                             0.21 (profiles/r04_pose_distribution.txt): AUTO keeps such fp32 launches of 1537-2048 strips (the
-                                            window that was measured: config 2) off the strip kernel; launches of up to 512 strips stay with it
-                                            whatever the hint (its 6-way plane split still wins there).  Like GMPI_FLAG_HINT_FRONTAL it never
-                                            changes a result.                                                                                */
+                                            window that was measured: config 2) off the strip kernel, and (round 5) 16-bit launches of 256-511
+                                            bands of 256 x 8 pixels off the band kernel's two-kernel path (a view it cannot stage costs such a
+                                            small launch ~18 us of table kernel and empty launches); launches of up to 512 strips stay with the
+                                            strip kernel whatever the hint (its 6-way plane split still wins there).  Like
+                                            GMPI_FLAG_HINT_FRONTAL it never changes a result.                                                */
     GMPI_FLAG_ALL = (1 << 7) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
 };
 

@@ -275,7 +275,10 @@ static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, 
     return GMPI_OK;
 }
 
-constexpr int64_t kAutoBandMin = 512;      // bf16: bands (of 256 x 8 pixels) from which AUTO takes the band kernel: two workgroups on every CU
+// bf16 / fp16: bands (of 256 x 8 pixels) from which AUTO takes the band kernel.  Round 5: 256 = one workgroup on every CU (rounds 3-4: 512 = two).
+// At 256 bands (two views of 512^2, eight of 256^2) the band kernel takes 0.115-0.125 ms where the strip / tile kernels take 0.140-0.146, whatever the
+// frontal hint says; at 128 bands it loses (0.122-0.133 against 0.078): profiles/r05_small_launches.txt.
+constexpr int64_t kAutoBandMin = 256;
 constexpr int64_t kAutoBandMinF32 = 1024;  // fp32: bands of 128 x 8 pixels (at 512 -- config 2 -- the strip kernel is as fast: profiles/r03_band_variants.txt)
 
 // does GMPI_VARIANT_AUTO consider the band kernel for this launch (given a workspace and the band kernel's alignment preconditions)?
@@ -331,12 +334,21 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
                          : params->rgba_dtype == GMPI_DTYPE_F32 ? (strips <= 512 || (strips > 1536 && strips <= 2048 && !tilted))
                                                                 : (strips <= 512 || (strips <= 2048 && frontal));
         variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
+        // (a launch the band kernel takes -- below -- is not "small", whatever the hints say: 16-bit volumes reach the band threshold at exactly the
+        //  2048 strips up to which a frontal hint would pick the strip kernel)
+        bool band_path = lds_ok && auto_takes_band(p, params->rgba_dtype) && band_variant_supports(p, params->rgba_dtype);
+        // ... unless the launch is in the range round 5 added (16-bit volumes, 256-511 bands) and the caller says that some camera is tilted beyond
+        // 0.53 rad: a view the band kernel cannot stage goes to the tile kernel behind a table kernel and an empty band launch, ~18 us that such a small
+        // launch feels (two views of 512^2 at 0.45 rad of yaw: 0.158 ms against the tile kernel's 0.140; the frontal ones 0.120 against 0.143)
+        if (band_path && tilted && params->rgba_dtype != GMPI_DTYPE_F32 &&
+            static_cast<int64_t>(p.N) * ((p.W + 255) / 256) * ((p.H + 7) / 8) < 512) band_path = false;
+        if (band_path) variant = GMPI_VARIANT_LDS;
         // Large launches over bf16 / fp32 volumes, when the caller lends a workspace: the band kernel (256 x 8 / 128 x 8 pixel bands, LDS-DMA;
         // 0.81 ms on BASELINE config 3 where the tile kernel takes 1.02, 1.21 against 1.33 with an fp32 volume) -- for the views it can stage.  Whether a view's texel boxes fit the band
         // kernel's buffers depends on the camera (tilt shears the boxes) and is only known on the device, so AUTO launches BOTH kernels and
         // lets the band kernel's table kernel share out the views through a gate word per view (KParams::gate): views with a box that does
         // not fit fall to the tile kernel, the others' tile workgroups exit at once (an empty second launch costs a few microseconds).
-        if (variant == GMPI_VARIANT_LDS && auto_takes_band(p, params->rgba_dtype) && band_variant_supports(p, params->rgba_dtype)) {
+        if (band_path) {
             static std::atomic<uint32_t> gate_counter{0x6d2b79f5u};
             uint32_t gen = gate_counter.fetch_add(1u, std::memory_order_relaxed);
             KParams pb = p;
