@@ -19,8 +19,8 @@
 // A band with a box that does not fit its buffers (strongly tilted camera) is rendered by the direct gather; GMPI_VARIANT_AUTO
 // hands the whole VIEW to the tile kernel instead (KParams::gate, gmpi_abi.hip).
 // Round 4 (profiles/r04_band_variants.txt): the plane step of the bf16 default-mode instances is software-pipelined -- a batch of 8 taps is
-// issued one batch ahead of the wait that lands it, the range check's read-back leads the pipeline -- and the loader offset lives in a
-// vector register.  What the measurements of that round say about the rest: a wave's own DMA is NOT what it waits for at the barrier (393 of
+// issued one batch ahead of the wait that lands it -- and the loader offset lives in a vector register.  (Round 5: the [0,1] test folds the landed
+// TAPS into a running maximum instead of reading every staged item back from LDS: the launch runs at the package power limit, see tap_fold8.)  What the measurements of that round say about the rest: a wave's own DMA is NOT what it waits for at the barrier (393 of
 // 4600 cycles per plane with or without memory traffic); the wait is the skew between the 16 waves; the scalar loads of the next step's
 // records belong BEHIND the last pixel (the waves that arrive first warm the scalar cache for the last one: issued at the top of the step
 // they cost 5 %), and the records of a plane must share one cache line across the sub-blocks for that to work (a plane-major table: +10 %).
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                                                          const uint4* __restrict__ recs, const uint4* __restrict__ pl, const uint32_t* __restrict__ hdr) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kNP = G::kNP;
-    constexpr int NSB = G::NSB, PPT = G::PPT, WPS = G::WPS, kSubLanes = G::kSubLanes, kThreads = G::kThreads;
+    constexpr int NSB = G::NSB, PPT = G::PPT, WPS = G::WPS, kSubLanes = G::kSubLanes;
     constexpr int kLineBytes = G::kLineBytes, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes, kBufBytes = G::kBufBytes;
     constexpr int kRPP = G::kRPP, kPassItems = G::kPassItems;
     constexpr bool BF = kES == 2;                              // 16-bit texels (bf16 or fp16): the two-pixel geometry, taps by ds_read_u16_d16_hi
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::kLdsBytes];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
-    const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)(smem + G::kOffBytes)));
+    const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)smem));  // the staging buffers lead the allocation (see coords(): a NaN coordinate reads THEM)
 
     // ---- blockIdx -> band.  XCD x = blockIdx % 8 gets a contiguous run of the bands of EVERY view (group of views that share an MPI): neighbours
     //      (column-major since round 5, see below) share halo rows in one L2, and the XCDs walk the views together (measured 4 % faster than one run of all bands per XCD,
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
         int l_col, l_line, l_row;
         bool l_on;
         loader_pos(l_col, l_line, l_row, l_on);
-        reinterpret_cast<uint32_t*>(smem)[tid] = static_cast<uint32_t>(l_row * s_row + (l_line & 3) * s_chan + kTPI * l_col) * static_cast<uint32_t>(kES);
+        reinterpret_cast<uint32_t*>(smem + 2 * kBufBytes)[tid] = static_cast<uint32_t>(l_row * s_row + (l_line & 3) * s_chan + kTPI * l_col) * static_cast<uint32_t>(kES);
     }
     const uint32_t pass_off = static_cast<uint32_t>(kRPP * s_row) * static_cast<uint32_t>(kES), pass_off2 = 2 * pass_off;           // per pass
     const uint32_t pass_off3 = 3 * pass_off, pass_off4 = 4 * pass_off;  // (kNP == 5 only)
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     const bool abl_noload = (p.flags & (1u << 16)) != 0, abl_nocomp = (p.flags & (1u << 17)) != 0, abl_noissue = (p.flags & (1u << 18)) != 0;
     // round 5, the "replay" of the plane step: bit 20 = no workgroup barrier, bit 21 = the records of the first planes stay (no scalar
     // loads in the loop) (KB_NOCHECK=1 in kbench drops the range check).  With 16 + 18 + 20 + 21 a wave runs the exact instruction stream of its pixels -- chain,
-    // counted waits, 32 two-byte taps, bilinear, blend, the read-back and its fold -- and nothing that ties it to the other fifteen waves.
+    // counted waits, 32 two-byte taps, bilinear, blend, the range check's fold -- and nothing that ties it to the other fifteen waves.
     const bool abl_nobar = (p.flags & (1u << 20)) != 0, abl_norec = (p.flags & (1u << 21)) != 0;
 #else
     constexpr bool abl_noload = false, abl_nocomp = false, abl_noissue = false, abl_nobar = false, abl_norec = false;
@@ -497,18 +497,17 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
             }
         };
 
-        // ---- [0,1] test of the landed items (mpi.py:185-187).  Every loader lane reads its own items back and folds their bit patterns into a
-        //      running unsigned maximum (non-negative floats order like unsigned integers: in [0,1] <=> pattern <= that of 1.0; the sign bit and
-        //      NaN / Inf compare above): 4 (bf16) / 2 (fp32) instructions per 16-byte item, no compare, no branch in the plane loop.  The staging
-        //      buffers are zero-filled once per band, so every byte a lane can read there is zero or a texel that some plane's loader brought in:
-        //      no masks.  The verdict is taken once per band (check_verdict below).
+        // ---- [0,1] test (mpi.py:185-187) on the TAPS: every texel the render samples passes through a tap register, and a tap register orders
+        //      like its value -- a 16-bit texel sits in the high half of a zeroed register (d16_hi), a 32-bit texel fills it; non-negative floats
+        //      order like unsigned integers, the sign bit and NaN / Inf compare above 1.0 -- so the test is a running unsigned maximum over the
+        //      tap registers: one v_max3_u32 per two taps, no compare, no branch in the plane loop; the verdict is taken once per band (below).
+        //      (Rounds 3-4 read every staged ITEM back from LDS instead -- 2 ds_read_b128 + 8 half-rate v_pk_max_u16 per lane and plane in
+        //      front of the pixels; round 5 found the launch running at the package power limit (1.39 of 1.40 kW, engine clock 2.02 of 2.4 GHz),
+        //      and dropping the read-back is worth 2.7 % on bf16 volumes, 1-2.5 % on fp32 ones: profiles/r05_power.txt.)
         uint32_t chk_acc = 0;
-        auto check_fold = [&](const u32x4& q) {
-            if (BF)  // two running maxima, one per 16-bit half (v_pk_max_u16: 1.8 ns per wave and SIMD; v_max3_u16 with op_sel measured 3.4 ns)
-                asm volatile("v_pk_max_u16 %0, %0, %1\n\tv_pk_max_u16 %0, %0, %2\n\tv_pk_max_u16 %0, %0, %3\n\tv_pk_max_u16 %0, %0, %4"
-                             : "+v"(chk_acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
-            else
-                asm volatile("v_max3_u32 %0, %0, %1, %2\n\tv_max3_u32 %0, %0, %3, %4" : "+v"(chk_acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+        auto tap_fold8 = [&](const uint32_t (&q)[8]) {
+            asm volatile("v_max3_u32 %0, %0, %1, %2\n\tv_max3_u32 %0, %0, %3, %4\n\tv_max3_u32 %0, %0, %5, %6\n\tv_max3_u32 %0, %0, %7, %8"
+                         : "+v"(chk_acc) : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
         };
 
         // ---- one pixel and plane, in three steps so that the taps of pixel q fly while the chain of pixel q + 1 issues ------------
@@ -541,8 +540,8 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                 const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
                 c.nw = wx0 * wy0, c.ne = wx1 * wy0, c.sw = wx0 * wy1, c.se = wx1 * wy1;
             }
-            // LDS byte address of the north-west tap of channel 0: two exact fp32 FMAs and one saturating conversion (NaN -> 0; an
-            // address past the allocation reads zeros): the box contains every tap of the sub-block (corner argument)
+            // LDS byte address of the north-west tap of channel 0: two exact fp32 FMAs and one saturating conversion (NaN -> 0: the head of
+            // the staging buffers, i.e. texels; an address past the allocation reads zeros): the box contains every tap of the sub-block (corner argument)
             const float af = __builtin_fmaf(fy, static_cast<float>(kRowBytes), __builtin_fmaf(fx, static_cast<float>(kES), rg.y));
             c.a_tap = static_cast<uint32_t>(af);
         };
@@ -606,20 +605,22 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
             uint32_t t[8];
             float smp[4];
             taps(ic<0>{}, c.a_tap, t);
+            if (check_range) tap_fold8(t);
             smp[0] = bilerp<STRICT>(tapf(t[0]), tapf(t[1]), tapf(t[2]), tapf(t[3]), f);
             smp[1] = bilerp<STRICT>(tapf(t[4]), tapf(t[5]), tapf(t[6]), tapf(t[7]), f);
             taps(ic<1>{}, c.a_tap, t);
+            if (check_range) tap_fold8(t);
             smp[2] = bilerp<STRICT>(tapf(t[0]), tapf(t[1]), tapf(t[2]), tapf(t[3]), f);
             smp[3] = bilerp<STRICT>(tapf(t[4]), tapf(t[5]), tapf(t[6]), tapf(t[7]), f);
             blend<STRICT>(A[q], smp[0], smp[1], smp[2], smp[3], c.s, dots[q]);
         };
 
 
-        // One plane step: barrier | DMA of plane t + 1 | this lane's landed items of plane t folded into the range check | the pixels | scalar
+        // One plane step: barrier | DMA of plane t + 1 | the pixels (their landed taps folded into the range check) | scalar
         // loads of the next step's records (box record of plane t + 2, plane constants of plane t + 1).
         // (Measured and not kept -- profiles/r03_band_variants.txt, r04_band_variants.txt: the loader offset fetched before the barrier;
         //  s_setprio around the DMA issue or by wave index; the record loads at the top of the step (+5 %: see the head of this file); the range
-        //  check at the end of the step (-1.4 %, superseded by the pipeline); non-temporal DMA (+5 %); the DMA passes spread over the step.)
+        //  check's former LDS read-back at the end of the step (-1.4 %; round 5 dropped the read-back); non-temporal DMA (+5 %); the DMA passes spread over the step.)
         uint4 Ln, Fc;      // wave-uniform: scalar registers
         uint32_t rhh_c, gp_c;
         uint32_t g_off = 0;  // this lane's loader offset: a vector register through the plane loop (round 3 re-read it from LDS behind every barrier)
@@ -633,105 +634,54 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
             constexpr int U = decltype(ub)::value;
             if (!abl_nobar) wg_barrier();  // own DMA of plane tt has landed -> everybody's has; everybody is done reading plane tt - 1
             GMPI_STAMP(0);
-            const uint32_t a_it = sub_base + static_cast<uint32_t>(fresh_tid() & (kSubLanes - 1)) * 16u;
-            // (loads and their wait in ONE statement unless noted: the compiler may copy an asm load's destination as soon as the statement ends)
-            u32x4 cq0, cq1, cq2, cq3, cq4;
-            const bool three_cur = three;  // set by the issue of this plane, one step ago
             if (tt + 1 < D && !abl_noissue) issue(Ln, g_off, ic<1 - U>{});
             GMPI_STAMP(3);
             const float4 rf = make_float4(__uint_as_float(Fc.x), __uint_as_float(Fc.y), __uint_as_float(Fc.z), __uint_as_float(Fc.w));
             // tap address constant of this plane and buffer (an integer below 2^24, exact in fp32)
             const float2 rg = make_float2(__uint_as_float(rhh_c), static_cast<float>(static_cast<int>(gp_c) + static_cast<int>(tile_base) + U * kBufBytes));
-            auto check_tail = [&]() {  // the last item of a lane (boxes of more than (kNP - 1) kRPP rows: rare)
-                if (three_cur) {
-                    constexpr int kTail = (kSubBytes - (kNP - 1) * kPassItems * 16) / 16;
-                    const uint32_t a_t = sub_base + static_cast<uint32_t>(min(fresh_tid() & (kSubLanes - 1), kTail - 1)) * 16u;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(cq4) : "v"(a_t), "i"(U * kBufBytes + (kNP - 1) * kPassItems * 16));
-                    check_fold(cq4);
-                }
-            };
-            // the read-back of the first kNP - 1 passes: issue (no wait) | land behind N younger LDS operations + fold
-            auto c_issue = [&]() {
-                if constexpr (kNP == 3)
-                    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-                                 : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                else
-                    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
-                                 : "=&v"(cq0), "=&v"(cq1), "=&v"(cq2), "=&v"(cq3)
-                                 : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16), "i"(U * kBufBytes + 2 * kPassItems * 16), "i"(U * kBufBytes + 3 * kPassItems * 16));
-            };
-            auto c_land = [&](auto nb) {
-                constexpr int N = decltype(nb)::value;
-                if constexpr (kNP == 3) {
-                    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(cq0), "+v"(cq1) : "i"(N));
-                    check_fold(cq0), check_fold(cq1);
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(cq0), "+v"(cq1), "+v"(cq2), "+v"(cq3) : "i"(N));
-                    check_fold(cq0), check_fold(cq1), check_fold(cq2), check_fold(cq3);
-                }
-                check_tail();
-            };
             if constexpr (piped) {
-                if (abl_nocomp) {
-                    if (check_range) {
-                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                        check_fold(cq0), check_fold(cq1);
-                        check_tail();
-                    }
-                } else {
-                    // LDS operations of the step, in issue order:  c (2 x b128, the range check's read-back) | b0 b1 (pixel 0: channels R G | B A) |
-                    // b2 b3 (pixel 1); every wait but the last leaves the 8 taps of the batch behind it in flight.
+                if (!abl_nocomp) {
+                    // LDS operations of the step, in issue order:  b0 b1 (pixel 0: channels R G | B A) | b2 b3 (pixel 1); every wait but the last
+                    // leaves the 8 taps of the batch behind it in flight.  A landed batch is folded into the range check's maximum (tap_fold8).
                     uint32_t ta[8], tb[8];
                     Coords p0, p1;
                     Footprint f;
                     float smp[4];
-                    // (measured, no difference: c at the END of the pipeline, its fold in the barrier wait of every wave but the last -- 0.8133 against 0.8123 ms)
-                    if (check_range) {
-                        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
-                                     : "=&v"(cq0), "=&v"(cq1) : "v"(a_it), "i"(U * kBufBytes), "i"(U * kBufBytes + kPassItems * 16));
-                    }
                     coords(0, rf, rg, p0);
                     taps_issue(ic<0>{}, p0.a_tap, ta);                                        // b0
-                    if (check_range) {
-                        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(cq0), "+v"(cq1) : "i"(8));  // c has landed (b0 may still fly)
-                        check_fold(cq0), check_fold(cq1);
-                        check_tail();
-                    }
                     taps_issue(ic<1>{}, p0.a_tap, tb);                                        // b1
                     coords(1, rf, rg, p1);                                                   // (the chain of pixel 1 issues while b0, b1 fly)
                     asm volatile("" : "+v"(p1.s), "+v"(p1.nw), "+v"(p1.ne), "+v"(p1.sw), "+v"(p1.se), "+v"(p1.a_tap));
                     taps_land(ic<8>{}, ta);
+                    if (check_range) tap_fold8(ta);
                     f.nw = p0.nw, f.ne = p0.ne, f.sw = p0.sw, f.se = p0.se;
                     smp[0] = bilerp<false>(tapf(ta[0]), tapf(ta[1]), tapf(ta[2]), tapf(ta[3]), f);
                     smp[1] = bilerp<false>(tapf(ta[4]), tapf(ta[5]), tapf(ta[6]), tapf(ta[7]), f);
                     asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));
                     taps_issue(ic<0>{}, p1.a_tap, ta);                                        // b2
                     taps_land(ic<8>{}, tb);
+                    if (check_range) tap_fold8(tb);
                     smp[2] = bilerp<false>(tapf(tb[0]), tapf(tb[1]), tapf(tb[2]), tapf(tb[3]), f);
                     smp[3] = bilerp<false>(tapf(tb[4]), tapf(tb[5]), tapf(tb[6]), tapf(tb[7]), f);
                     blend<false>(A[0], smp[0], smp[1], smp[2], smp[3], p0.s, dots[0]);
                     asm volatile("" : "+v"(A[0].T), "+v"(A[0].r), "+v"(A[0].g), "+v"(A[0].b), "+v"(A[0].z));
                     taps_issue(ic<1>{}, p1.a_tap, tb);                                        // b3
                     taps_land(ic<8>{}, ta);
+                    if (check_range) tap_fold8(ta);
                     f.nw = p1.nw, f.ne = p1.ne, f.sw = p1.sw, f.se = p1.se;
                     smp[0] = bilerp<false>(tapf(ta[0]), tapf(ta[1]), tapf(ta[2]), tapf(ta[3]), f);
                     smp[1] = bilerp<false>(tapf(ta[4]), tapf(ta[5]), tapf(ta[6]), tapf(ta[7]), f);
                     asm volatile("" : "+v"(smp[0]), "+v"(smp[1]));  // (pins the two samples in front of the last wait)
                     taps_land(ic<0>{}, tb);
+                    if (check_range) tap_fold8(tb);
                     smp[2] = bilerp<false>(tapf(tb[0]), tapf(tb[1]), tapf(tb[2]), tapf(tb[3]), f);
                     smp[3] = bilerp<false>(tapf(tb[4]), tapf(tb[5]), tapf(tb[6]), tapf(tb[7]), f);
                     blend<false>(A[1], smp[0], smp[1], smp[2], smp[3], p1.s, dots[1]);
                 }
             } else if constexpr (pipedG) {
-                // any PPT: c | A0 B0 | A1 B1 | ... (A = channels R G of a pixel, B = B A); every wait but the last leaves one batch in flight
+                // any PPT: A0 B0 | A1 B1 | ... (A = channels R G of a pixel, B = B A); every wait but the last leaves one batch in flight
                 constexpr int NB = BF ? 8 : 4;  // LDS operations per batch
-                if (abl_nocomp) {
-                    if (check_range) {
-                        c_issue();
-                        c_land(ic<0>{});
-                    }
-                } else {
+                if (!abl_nocomp) {
                     uint32_t ta[8], tb[8];
                     u32x2_t va[4], vb[4];
                     Coords pc, pn;
@@ -748,10 +698,12 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                     auto landA = [&](auto nb) {
                         if constexpr (BF) {
                             taps_land(nb, ta);
+                            if (check_range) tap_fold8(ta);
                             smp[0] = bilerp<false>(tapf(ta[0]), tapf(ta[1]), tapf(ta[2]), tapf(ta[3]), f);
                             smp[1] = bilerp<false>(tapf(ta[4]), tapf(ta[5]), tapf(ta[6]), tapf(ta[7]), f);
                         } else {
                             taps32_land(nb, va);
+                            if (check_range) { const uint32_t q8[8] = {va[0].x, va[0].y, va[1].x, va[1].y, va[2].x, va[2].y, va[3].x, va[3].y}; tap_fold8(q8); }
                             smp[0] = bilerp<false>(__uint_as_float(va[0].x), __uint_as_float(va[0].y), __uint_as_float(va[1].x), __uint_as_float(va[1].y), f);
                             smp[1] = bilerp<false>(__uint_as_float(va[2].x), __uint_as_float(va[2].y), __uint_as_float(va[3].x), __uint_as_float(va[3].y), f);
                         }
@@ -760,10 +712,12 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                     auto landB = [&](auto nb) {
                         if constexpr (BF) {
                             taps_land(nb, tb);
+                            if (check_range) tap_fold8(tb);
                             smp[2] = bilerp<false>(tapf(tb[0]), tapf(tb[1]), tapf(tb[2]), tapf(tb[3]), f);
                             smp[3] = bilerp<false>(tapf(tb[4]), tapf(tb[5]), tapf(tb[6]), tapf(tb[7]), f);
                         } else {
                             taps32_land(nb, vb);
+                            if (check_range) { const uint32_t q8[8] = {vb[0].x, vb[0].y, vb[1].x, vb[1].y, vb[2].x, vb[2].y, vb[3].x, vb[3].y}; tap_fold8(q8); }
                             smp[2] = bilerp<false>(__uint_as_float(vb[0].x), __uint_as_float(vb[0].y), __uint_as_float(vb[1].x), __uint_as_float(vb[1].y), f);
                             smp[3] = bilerp<false>(__uint_as_float(vb[2].x), __uint_as_float(vb[2].y), __uint_as_float(vb[3].x), __uint_as_float(vb[3].y), f);
                         }
@@ -786,10 +740,8 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                             pc = pn;
                         }
                     };
-                    if (check_range) c_issue();
                     coords(0, rf, rg, pc);
                     issueA(pc);
-                    if (check_range) c_land(ic<NB>{});  // c has landed (A0 may still fly)
                     issueB(pc);
                     px_step(ic<0>{});
                     if constexpr (PPT > 1) px_step(ic<1>{});
@@ -798,11 +750,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                     static_assert(PPT <= 4, "pixel slots");
                 }
             } else {
-                if (check_range) {
-                    c_issue();
-                    c_land(ic<0>{});
-                    GMPI_STAMP(2);
-                }
+                GMPI_STAMP(2);
                 if (!abl_nocomp) {
 #pragma unroll
                     for (int q = 0; q < PPT; ++q) {
@@ -824,11 +772,8 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
 #pragma unroll
         for (int q = 0; q < PPT; ++q)
             asm volatile("" : "+v"(rx[q]), "+v"(ry[q]), "+v"(rz[q]), "+v"(rcp_rz[q]), "+v"(A[q].T), "+v"(A[q].r), "+v"(A[q].g), "+v"(A[q].b), "+v"(A[q].z));
-        if (check_range) {  // zero-fill of the staging buffers (see check_fold)
-            for (int i = tid; i < 2 * kBufBytes / 16; i += kThreads) reinterpret_cast<uint4*>(smem + G::kOffBytes)[i] = make_uint4(0, 0, 0, 0);
-        }
-        __syncthreads();  // (also: the loader offsets are in place)
-        g_off = reinterpret_cast<const uint32_t*>(smem)[fresh_tid()];
+        __syncthreads();  // (the loader offsets are in place)
+        g_off = reinterpret_cast<const uint32_t*>(smem + 2 * kBufBytes)[fresh_tid()];
         issue(myrec[0], g_off, ic<0>{});  // plane 0
         Fc = mypl[0], rhh_c = mypl[1].x, gp_c = myrec[0].w, Ln = myrec[kRecStep];
         for (int t = 0; t < D; t += 2) {
@@ -839,7 +784,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
         //      says nothing about the values below it, so such a band re-tests its texels one by one (cold: never for generator output) ----
         if (check_range) {
             constexpr uint32_t kOne = F16 ? 0x3c00u : BF ? 0x3f80u : 0x3f800000u, kNegZero = BF ? 0x8000u : 0x80000000u;  // (the pattern of 1.0 / -0.0 in the storage type)
-            const uint32_t mx = BF ? max(chk_acc & 0xffffu, chk_acc >> 16) : chk_acc;
+            const uint32_t mx = BF ? chk_acc >> 16 : chk_acc;   // (a 16-bit tap's register: the texel in the high half, zeros below)
 #ifdef GMPI_TUNE
             if (p.status != nullptr && mx > kOne) { atomicMax(p.status + 1, mx); atomicMax(p.status + 2, static_cast<uint32_t>(band_id)); atomicMax(p.status + 3, static_cast<uint32_t>(tid)); }
 #endif
@@ -849,7 +794,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                     int l_col, l_line, l_row;
                     bool l_on;
                     loader_pos(l_col, l_line, l_row, l_on);
-                    const uint32_t g0 = reinterpret_cast<const uint32_t*>(smem)[fresh_tid()];
+                    const uint32_t g0 = reinterpret_cast<const uint32_t*>(smem + 2 * kBufBytes)[fresh_tid()];
                     bool lane_bad = false;
                     for (int t = 0; t < D; ++t) {
                         const uint4 rl = myrec[static_cast<int64_t>(t) * kRecStep];
