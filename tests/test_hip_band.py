@@ -96,6 +96,23 @@ def test_band_range_check_fp16():
     assert int(out["status"][0]) == 0 and np.array_equal(out["color"], oracle.render(nz.float(), dhw, ray, eye, zd)["color"])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
+def test_band_range_check_sees_every_sampled_texel(dtype):
+    """The band kernel's [0,1] test runs on the taps (late round 5: a running maximum over the tap registers instead of an LDS read-back of the
+    staged items): ONE bad texel in view -- any channel, i.e. either tap batch; rows that fall to either pixel of a thread -- trips it."""
+    rgba, dhw, ray, eye, zd = _random_case(seed=76, B=2, D=5, S=256)
+    vol = rgba.to(dtype)
+    assert int(hip_render(vol, dhw, ray, eye, zd, variant="band")["status"][0]) == 0
+    for i, (c, y, x, value) in enumerate([(0, 120, 120, 1.5), (1, 125, 77, -0.25), (2, 131, 190, float("nan")), (3, 122, 141, 1.0078125),
+                                          (0, 99, 160, float("inf")), (3, 140, 101, -1e-3)]):
+        bad = vol.clone()
+        bad[i % 2, i % 5, c, y, x] = value
+        with pytest.raises(AssertionError):
+            hip_render(bad, dhw, ray, eye, zd, variant="band")
+        with pytest.raises(AssertionError):
+            hip_render(bad, dhw, ray, eye, zd, variant="band", strict=True)
+
+
 def test_auto_shares_views_between_band_and_tile_kernels():
     """A launch large enough for AUTO's band path (>= gmpi_query(9) bands) whose views are partly frontal, partly tilted beyond what the band
     kernel stages: every view must come out once, bit-exact, whichever kernel the device-side gate hands it to."""
