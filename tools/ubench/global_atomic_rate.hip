@@ -49,6 +49,42 @@ template <int MODE> void run(const char* name, float* d, uint64_t n, int len, in
            lanes / ms / 1e6, instr / ms / 1e6, instr * seg / ms / 1e6, lanes * 4 / ms / 1e6);
 }
 
+__global__ __launch_bounds__(256) void kmix(float* __restrict__ buf, const uint64_t n_floats, const int mix) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    // lanes 0-15: segment 0 of a line, lanes 16-31: segment 1; lanes 32-63: the same for the wave's next line
+    const uint64_t base = (static_cast<uint64_t>(wave) * kLines * 64) % (n_floats - kLines * 64 - 64);
+    float* p = buf + base + lane;
+    const float v = 1.0f + lane;
+    const int seg = (lane >> 4) & 1, line_par = lane >> 5;
+#pragma unroll 4
+    for (int i = 0; i < kLines; ++i) {
+        float* q = p + i * 64;
+        bool st;
+        if (mix == 0) st = false;
+        else if (mix == 1) st = true;
+        else if (mix == 2) st = line_par == 1;
+        else st = seg == 1;
+        if (st) __builtin_nontemporal_store(v, q);
+        else atomicAdd(q, v);
+    }
+}
+void run_mix(float* d, uint64_t n, int mix) {
+    hipEvent_t a, b;
+    hipEventCreate(&a), hipEventCreate(&b);
+    const int blocks = 256 * 32;
+    hipLaunchKernelGGL(kmix, dim3(blocks), dim3(256), 0, 0, d, n, mix);
+    hipEventRecord(a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kmix, dim3(blocks), dim3(256), 0, 0, d, n, mix);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    ms /= 3;
+    const double segs = double(blocks) * 4 * kLines * 4;
+    const char* names[4] = {"all atomics", "all stores", "atomic LINES | stored LINES", "atomic segment | stored segment in every line"};
+    printf("mix %-48s %7.3f ms  %6.1f G segments/s\n", names[mix], ms, segs / ms / 1e6);
+}
+
 int main() {
     const uint64_t n = 1ull << 29;  // 2 GiB of floats
     float* d;
@@ -64,5 +100,11 @@ int main() {
         r(16, 1024, 1);
         r(8, 1024, 1);
     }
+    // MIXES (would a flush that stores the segments only its own tile touches and adds the rest be faster?): every wave issues, per line, one
+    // instruction of 16 lanes = one segment; a line is 32 floats = one 128-byte cache line.
+    run_mix(d, n, 0);   // all atomics, both segments of every line
+    run_mix(d, n, 1);   // all stores
+    run_mix(d, n, 2);   // even LINES atomics, odd lines stores (no line gets both)
+    run_mix(d, n, 3);   // first segment of every line atomic, second segment stored (every line gets both, no segment does)
     return 0;
 }
