@@ -651,6 +651,54 @@ def companion_lines(a, dev, main_name):
     return res
 
 
+def power_probe(step, sync, gpu_index, seconds=1.5):
+    """Engine clock and package power WHILE the timed launch loops (outside the timed region, rank 0): the render launches of this path run at the
+    package power limit (profiles/r05_power.txt), so `ms_per_step` depends on the clock the box's firmware grants at its cap -- this block is the
+    witness on the box that produced the line.  Samples `rocm-smi` from a thread while the main thread keeps the launch queue full; None when the tool
+    is missing or prints something else."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.isfile(smi):
+        return None
+    samples, done = [], threading.Event()
+
+    def sampler():
+        time.sleep(0.4)   # the clock has settled under the loop by then
+        for _ in range(4):
+            try:
+                out = subprocess.run([smi, "-d", str(gpu_index), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+            except Exception:  # noqa: BLE001
+                break
+            m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            w = re.search(r"Package Power \(W\): ([\d.]+)", out)
+            if m and w:
+                samples.append((int(m.group(1)), float(w.group(1))))
+        done.set()
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while not done.is_set() and time.perf_counter() - t0 < 20.0:
+        for _ in range(16):
+            step()
+        sync()
+    th.join(timeout=15)
+    if not samples:
+        return None
+    cap = None
+    try:
+        out = subprocess.run([smi, "-d", str(gpu_index), "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", out)
+        cap = float(m.group(1)) if m else None
+    except Exception:  # noqa: BLE001
+        pass
+    return {"engine_mhz": [c for c, _ in samples], "package_w": [w for _, w in samples], "cap_w": cap, "engine_mhz_max": 2400,
+            "what": "rocm-smi sampled while the timed launch loops (outside the timed region): at the cap the firmware sets the engine clock, and with it ms_per_step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -670,13 +718,14 @@ def main():
                     help="for rocprofv3 (tools/prof.sh): the render kernels are launched W + K times and never else -- the clock ramp runs on another "
                          "kernel (the stream probe), no parity / pose sweep / end-to-end / companions / CPU baseline -- so that the average of the "
                          "kernel-trace CSV IS roofline.kernel_ms")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the `power` block (engine clock / package power under the timed launch, rocm-smi, rank 0, outside the timed region)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--prewarm-ms", type=float, default=250.0,
                     help="untimed render launches for this long before the W warm-up steps: a GPU coming from idle needs ~0.1 s to reach "
                          "its busy clocks (20 steps are only 23 ms of work); 0 disables")
     a = ap.parse_args()
     if a.profile_clean:
-        a.no_parity, a.pose_draws, a.no_cpu_baseline, a.no_companions = True, 0, True, True
+        a.no_parity, a.pose_draws, a.no_cpu_baseline, a.no_companions, a.no_power_probe = True, 0, True, True, True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -706,7 +755,7 @@ def main():
     if dry:
         dry_lib = _DryLibrary()
         _lib.load_library = lambda: dry_lib
-        a.no_parity, a.pose_draws, a.no_cpu_baseline, a.prewarm_ms, a.no_companions = True, 0, True, 0.0, True
+        a.no_parity, a.pose_draws, a.no_cpu_baseline, a.prewarm_ms, a.no_companions, a.no_power_probe = True, 0, True, 0.0, True, True
     Event = _WallEvent if dry else torch.cuda.Event
 
     def sync():
@@ -757,6 +806,11 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
         r.mpi.raise_on_status(status)  # asserts of all steps, one read-back
+        power = None
+        if rank == 0 and not a.no_power_probe:
+            with torch.no_grad():
+                power = power_probe(step, sync, local_rank)
+            r.mpi.raise_on_status(status)
         if not a.profile_clean:
             # end-to-end MPIRenderer.render() as a caller gets it by default: pose sampling on the host + rays + launch + the status read-back
             # in the call (status_mode="sync": the reference's assertion timing)
@@ -891,7 +945,7 @@ def main():
                          # what a user of the pose distribution sees: the same bytes over the MEAN launch time of the `pose_sweep` draws
                          "frac_pose_mean": None if not sweep else round(abytes / (sweep["mean_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
-            "pose_sweep": sweep, "numa_pin": pinned,
+            "pose_sweep": sweep, "numa_pin": pinned, "power": power,
         }
         if e2e is not None:
             line.update({"e2e_render_ms": round(e2e["mean"], 3), "e2e_render_max_ms": round(e2e["max"], 3),
