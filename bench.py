@@ -651,6 +651,14 @@ def companion_lines(a, dev, main_name):
     return res
 
 
+def parse_smi(out):
+    """(engine MHz, package W) out of `rocm-smi --showclocks --showpower`, or None."""
+    import re
+    m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+    w = re.search(r"Package Power \(W\): ([\d.]+)", out)
+    return (int(m.group(1)), float(w.group(1))) if m and w else None
+
+
 def power_probe(step, sync, gpu_index, seconds=1.5):
     """Engine clock and package power WHILE the timed launch loops (outside the timed region, rank 0): the render launches of this path run at the
     package power limit (profiles/r05_power.txt), so `ms_per_step` depends on the clock the box's firmware grants at its cap -- this block is the
@@ -672,10 +680,9 @@ def power_probe(step, sync, gpu_index, seconds=1.5):
                 out = subprocess.run([smi, "-d", str(gpu_index), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
             except Exception:  # noqa: BLE001
                 break
-            m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
-            w = re.search(r"Package Power \(W\): ([\d.]+)", out)
-            if m and w:
-                samples.append((int(m.group(1)), float(w.group(1))))
+            got = parse_smi(out)
+            if got:
+                samples.append(got)
         done.set()
 
     th = threading.Thread(target=sampler, daemon=True)
