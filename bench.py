@@ -260,35 +260,151 @@ def run_video(a, dev, rank, world, use_dist):
         dist.destroy_process_group()
 
 
-def run_train(a, dev, rank, world, use_dist):
-    """--workload train256 | train512 | train1024: the render of the reference's G-step (train.py:740-779: `MPIRenderer.render` on the generator's
-    RGBA volume under autograd, a loss on the frames, `.backward()`), at the curriculum's shapes (curriculums.py:89-91: 32 planes, batch 8 / 4 / 4).
-    A "step" = forward launch (colour, depth, transmittance) + zero-fill of the gradient volume + `gmpi_mpi_render_backward_launch`, exactly what
-    `hip_mpi._RenderFunction` enqueues (driven here through the product's own autograd bridge: `render()` on a volume that requires grad, then
-    `torch.autograd.backward` with fixed upstream gradients).  Each part is also timed alone with HIP events.
-    Algorithmic bytes of the step: volume read by the forward + volume read by the backward + gradient volume written (fp32, 16 B per texel and
-    sweep) + per pixel: rays 12 + frames out 20 (forward), rays 12 + upstream gradients 16 + transmittance 4 (backward).  The zero-fill the C ABI
-    asks of the caller and the read half of the atomics' read-modify-write are traffic, not algorithm: they show in `traffic`, not in `achieved`."""
-    import ctypes
-    import ml_gmpi_amd
-    from ml_gmpi_amd import _lib
-    preset, S, D, B, desc = TRAIN_WORKLOADS[a.workload]
-    r = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=a.variant, on_out_of_plane="raise")
-    r.set_cam(r.cam_fov, S, S)
-    g = torch.Generator(device=dev).manual_seed(7000 + rank)
-    rgba = torch.rand((B, D, 4, S, S), device=dev, generator=g)
-    rgba[:, -1, 3] = 1.0
-    rgba.requires_grad_(True)
-    g_color = torch.randn((B, 3, S, S), device=dev, generator=g)
-    g_depth = torch.randn((B, 1, S, S), device=dev, generator=g)
-    torch.manual_seed(3)
-    cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
-    infos = dict(zip(["batch_yaws", "batch_pitches", "batch_tf_c2w", "batch_ray_dir", "batch_eye_pos", "batch_z_dir"], cam))
+class TrainWorkload:
+    """The render of the reference's G-step (train.py:740-779: `MPIRenderer.render` on the generator's RGBA volume under autograd, a loss on the
+    frames, `.backward()`) at one of the curriculum's shapes (curriculums.py:89-91: 32 planes, batch 8 / 4 / 4), set up on a device.
+    `step()` = forward launch (colour, depth, transmittance) + zero-fill of the gradient volume + `gmpi_mpi_render_backward_launch`, exactly what
+    `hip_mpi._RenderFunction` enqueues (driven through the product's own autograd bridge); `parts()` times each of the three alone through the C ABI."""
 
-    def step():
-        rgba.grad = None
-        color, depth, _, _ = r.render(rgba, S, S, given_cam_infos=infos, defer_status=True)
-        torch.autograd.backward([color, depth], [g_color, g_depth])
+    def __init__(self, name, dev, rank=0, variant="auto"):
+        import ml_gmpi_amd
+        preset, S, D, B, desc = TRAIN_WORKLOADS[name]
+        self.name, self.S, self.D, self.B, self.desc, self.dev, self.variant = name, S, D, B, desc, dev, variant
+        r = self.r = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=variant, on_out_of_plane="raise")
+        r.set_cam(r.cam_fov, S, S)
+        g = torch.Generator(device=dev).manual_seed(7000 + rank)
+        rgba = torch.rand((B, D, 4, S, S), device=dev, generator=g)
+        rgba[:, -1, 3] = 1.0
+        self.rgba = rgba.requires_grad_(True)
+        self.g_color = torch.randn((B, 3, S, S), device=dev, generator=g)
+        self.g_depth = torch.randn((B, 1, S, S), device=dev, generator=g)
+        torch.manual_seed(3)
+        cam = r.sample_cam_poses(B, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True)
+        self.infos = dict(zip(["batch_yaws", "batch_pitches", "batch_tf_c2w", "batch_ray_dir", "batch_eye_pos", "batch_z_dir"], cam))
+        self.ray, self.eye, self.zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+        self.dhw = r._dhw_on_device().expand(B, -1, -1).contiguous()
+        vol_b, pix = B * D * 4 * S * S * 4, B * S * S
+        # algorithmic bytes: volume read by the forward | volume read by the backward + gradient volume written; per pixel rays 12 + frames out 20
+        # (forward), rays 12 + upstream gradients 16 + transmittance 4 (backward)
+        self.ab_fwd, self.ab_bwd = vol_b + pix * (12 + 20), 2 * vol_b + pix * (12 + 16 + 4)
+        self._abi = None
+
+    def step(self):
+        self.rgba.grad = None
+        color, depth, _, _ = self.r.render(self.rgba, self.S, self.S, given_cam_infos=self.infos, defer_status=True)
+        torch.autograd.backward([color, depth], [self.g_color, self.g_depth])
+
+    def abi(self):
+        """The step's launches through the C ABI (what the bridge enqueues): fwd(), and bwd(g_color, g_depth, grad) on a parameter struct of the forward."""
+        if self._abi is None:
+            import ctypes
+            from ml_gmpi_amd import _lib
+            lib = _lib.load_library()
+            B, S, dev = self.B, self.S, self.dev
+            out = dict(color=torch.empty((B, 3, S, S), device=dev), depth=torch.empty((B, 1, S, S), device=dev), T=torch.empty((B, 1, S, S), device=dev))
+            status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+            vol = self.rgba.detach()
+
+            def fwd(variant=None):
+                mpi = self.r.mpi
+                was = mpi.variant
+                if variant is not None:
+                    mpi.variant = variant
+                try:
+                    return mpi.render_views(vol, self.dhw, self.ray, self.eye, self.zd, views_per_mpi=1, check_last_plane=True, out_pm1=True,
+                                            want_transmittance=True, status=status, defer_status=True, out=out, _in_autograd_fn=True)
+                finally:
+                    mpi.variant = was
+            pstruct, keep = fwd()["_bwd"]
+            pstruct.rgb_out = pstruct.depth_out = pstruct.status = None
+            pstruct.flags |= _lib.FLAG_GRAD_ZEROED   # (what the autograd bridge passes: every step zero-fills the gradient volume first)
+            grad = torch.zeros_like(vol)
+            gstride = (ctypes.c_int64 * 5)(*grad.stride())
+            cs = torch.cuda.current_stream(dev).cuda_stream
+
+            def bwd(gc=self.g_color, gd=self.g_depth, into=grad, variant=None):
+                was = pstruct.variant
+                if variant is not None:
+                    pstruct.variant = _lib.VARIANTS[variant]
+                try:
+                    _lib.check(lib.gmpi_mpi_render_backward_launch(ctypes.byref(pstruct), gc.data_ptr(), gd.data_ptr(), into.data_ptr(), gstride, cs),
+                               "gmpi_mpi_render_backward_launch")
+                finally:
+                    pstruct.variant = was
+            self._abi = dict(fwd=fwd, bwd=bwd, grad=grad, status=status, keep=keep, pstruct=pstruct)
+        return self._abi
+
+    def parts(self, n=20):
+        """Each part alone: n launches behind 3 warm-ups, HIP events on the launch stream."""
+        k = self.abi()
+        dev = self.dev
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+            for e0, e1 in evs:
+                e0.record(); fn(); e1.record()
+            torch.cuda.synchronize(dev)
+            return sum(e0.elapsed_time(e1) for e0, e1 in evs) / n
+        with torch.no_grad():
+            fwd_ms, zero_ms, bwd_ms = timed(k["fwd"]), timed(k["grad"].zero_), timed(k["bwd"])
+        self.r.mpi.raise_on_status(k["status"])
+        return dict(forward_ms=round(fwd_ms, 4), forward_frac=round(self.ab_fwd / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    grad_zero_fill_ms=round(zero_ms, 4), backward_ms=round(bwd_ms, 4),
+                    backward_frac=round(self.ab_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), backward_algorithmic_bytes=self.ab_bwd,
+                    what=f"each part alone: {n} launches, HIP events on the launch stream")
+
+    def parity(self, n_windows=2, w=64):
+        """The backward against (1) the all-atomic one-pixel-per-lane kernel (GMPI_VARIANT_GATHER: no staging, no tiles, 16 global fp32 atomics per
+        pixel and plane) on the TIMED launch's own upstream gradients -- the whole gradient volume -- and (2) the reference's own op chain under
+        torch autograd on the host (oracle/torch_ops.py: F.grid_sample, cumprod, the reference's sums; fp32) for upstream gradients restricted to one
+        w x w pixel window per checked view (a full 1024^2 view would need minutes and 20 GB on the host): the same kernel, volume, cameras and
+        transmittance input; errors relative to the largest gradient.  Bars: 1e-5 (kernel against kernel, both fp32 sums in different orders),
+        5e-5 (fp32 host chain on white noise; tests/test_hip_backward.py pins the same quantity on the reference's fixtures at 3e-5)."""
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import torch_ops
+        k = self.abi()
+        dev, S, B = self.dev, self.S, self.B
+        with torch.no_grad():
+            k["fwd"]()                                   # (the transmittance the backward starts from)
+            k["grad"].zero_(); k["bwd"]()
+            other = torch.zeros_like(k["grad"])
+            k["bwd"](into=other, variant="gather")
+            torch.cuda.synchronize(dev)
+            scale = float(other.abs().max())
+            err_kernel = float((k["grad"] - other).abs().max()) / scale
+            del other
+        err_ref = 0.0
+        for i in range(min(n_windows, B)):
+            n = (i * 3) % B
+            y0, x0 = (S // 2 - w // 2, min(S // 2 + 7, S - w)) if i % 2 == 0 else (S - w, 0)
+            gc, gd = torch.zeros_like(self.g_color), torch.zeros_like(self.g_depth)
+            gc[n, :, y0:y0 + w, x0:x0 + w] = self.g_color[n, :, y0:y0 + w, x0:x0 + w]
+            gd[n, :, y0:y0 + w, x0:x0 + w] = self.g_depth[n, :, y0:y0 + w, x0:x0 + w]
+            with torch.no_grad():
+                k["grad"].zero_(); k["bwd"](gc=gc, gd=gd)
+                got = k["grad"][n].cpu()
+            vol = self.rgba.detach()[n:n + 1].cpu().requires_grad_(True)
+            color, depth = torch_ops.mpi_forward(vol, self.dhw[n:n + 1].cpu(), self.ray[n:n + 1, :, y0:y0 + w, x0:x0 + w].contiguous().cpu(),
+                                                 self.eye[n:n + 1].cpu(), self.zd[n:n + 1].cpu())
+            # (the forward hands out 2 c - 1, mpi_renderer.py:467: the upstream gradient of the frame reaches c doubled)
+            loss = (2.0 * color * gc[n:n + 1, :, y0:y0 + w, x0:x0 + w].cpu()).sum() + (depth * gd[n:n + 1, :, y0:y0 + w, x0:x0 + w].cpu()).sum()
+            loss.backward()
+            ref = vol.grad[0]
+            err_ref = max(err_ref, float((got - ref).abs().max()) / float(ref.abs().max()))
+        return dict(ok=bool(err_kernel <= 1e-5 and err_ref <= 5e-5), vs_all_atomic_kernel=float(f"{err_kernel:.3e}"), vs_reference_autograd=float(f"{err_ref:.3e}"),
+                    bars=[1e-5, 5e-5], windows=f"{min(n_windows, B)} views x one {w}x{w} pixel window of upstream gradients vs oracle/torch_ops.py under torch autograd (host, fp32); "
+                                               "the timed launch's full gradient vs GMPI_VARIANT_GATHER", scale="relative to the largest |gradient|")
+
+
+def run_train(a, dev, rank, world, use_dist):
+    """--workload train256 | train512 | train1024: see TrainWorkload.  The zero-fill the C ABI asks of the caller and the read half of the atomics'
+    read-modify-write are traffic, not algorithm: they show in `traffic`, not in `achieved`."""
+    from ml_gmpi_amd import _lib
+    w = TrainWorkload(a.workload, dev, rank, a.variant)
+    S, D, B, desc = w.S, w.D, w.B, w.desc
+    step = w.step
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -310,53 +426,22 @@ def run_train(a, dev, rank, world, use_dist):
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / a.steps
-    grad_ref = rgba.grad.detach().clone()
+    grad_ref = w.rgba.grad.detach().clone()
 
-    # ---- the parts alone, through the C ABI (what the bridge enqueues), HIP events around each ----
-    lib = _lib.load_library()
-    ray, eye, zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
-    dhw = r._dhw_on_device().expand(B, -1, -1).contiguous()
-    out = dict(color=torch.empty((B, 3, S, S), device=dev), depth=torch.empty((B, 1, S, S), device=dev), T=torch.empty((B, 1, S, S), device=dev))
-    status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
-    vol = rgba.detach()
-
-    def fwd():
-        return r.mpi.render_views(vol, dhw, ray, eye, zd, views_per_mpi=1, check_last_plane=True, out_pm1=True, want_transmittance=True,
-                                  status=status, defer_status=True, out=out, _in_autograd_fn=True)
-    res = fwd()
-    pstruct, keep = res["_bwd"]
-    pstruct.rgb_out = pstruct.depth_out = pstruct.status = None
-    grad = torch.zeros_like(vol)
-    gstride = (ctypes.c_int64 * 5)(*grad.stride())
-    cs = torch.cuda.current_stream(dev).cuda_stream
-
-    def bwd():
-        _lib.check(lib.gmpi_mpi_render_backward_launch(ctypes.byref(pstruct), g_color.data_ptr(), g_depth.data_ptr(), grad.data_ptr(), gstride, cs),
-                   "gmpi_mpi_render_backward_launch")
-
-    def timed(fn, n=20):
-        for _ in range(3):
-            fn()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        for e0, e1 in evs:
-            e0.record(); fn(); e1.record()
-        torch.cuda.synchronize(dev)
-        return sum(e0.elapsed_time(e1) for e0, e1 in evs) / n
+    parts = w.parts()
+    k = w.abi()
     with torch.no_grad():
-        fwd_ms, zero_ms, bwd_ms = timed(fwd), timed(grad.zero_), timed(bwd)
-        grad.zero_(); bwd()
+        k["grad"].zero_(); k["bwd"]()
         torch.cuda.synchronize(dev)
-        same = float((grad - grad_ref).abs().max() / grad_ref.abs().max())   # (atomics: the order of the adds differs from run to run)
-    r.mpi.raise_on_status(status)
+        same = float((k["grad"] - grad_ref).abs().max() / grad_ref.abs().max())   # (atomics: the order of the adds differs from run to run)
+    del grad_ref
 
     t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
     if rank == 0:
-        vol_b = B * D * 4 * S * S * 4
-        pix = B * S * S
-        ab_fwd, ab_bwd = vol_b + pix * (12 + 20), 2 * vol_b + pix * (12 + 16 + 4)
+        ab_fwd, ab_bwd = w.ab_fwd, w.ab_bwd
         step_ms = max(kern_ms, elapsed / a.steps * 1e3)
         ach = (ab_fwd + ab_bwd) / (step_ms * 1e-3) / 1e9
         traffic = None
@@ -375,16 +460,20 @@ def run_train(a, dev, rank, world, use_dist):
                            "rgba_storage": "f32", "variant": a.variant, "parallelism": f"batch sharded x{world}", "step": "forward + zero-fill + backward, via autograd"},
                 "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                              "priced_on_ms": round(step_ms, 4), "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": ab_fwd + ab_bwd, "traffic": traffic,
-                             "parts": {"forward_ms": round(fwd_ms, 4), "forward_frac": round(ab_fwd / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "grad_zero_fill_ms": round(zero_ms, 4),
-                                       "backward_ms": round(bwd_ms, 4), "backward_frac": round(ab_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                       "backward_algorithmic_bytes": ab_bwd, "what": "each part alone: 20 launches, HIP events on the launch stream"}},
+                             "parts": parts},
                 "backward_repeatability": {"max_abs_diff_over_max_grad": float(f"{same:.3e}"), "what": "two runs of the backward (atomic adds in a different order)"},
                 "cpu_baseline": None}
+        if not a.no_parity:
+            line["parity"] = w.parity()
         print(json.dumps(line), flush=True)
+        parity_failed = bool(line.get("parity")) and not line["parity"]["ok"]
+    else:
+        parity_failed = False
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: the backward does not match its references (see `parity` in the line above)")
 
 
 class _DryLibrary:
@@ -419,34 +508,53 @@ class _WallEvent:
         return (other.t - self.t) * 1e3
 
 
-def numa_pin(local_rank: int, enable: bool):
+def numa_cpus_of_pci(pci: str, sysfs: str = "/sys"):
+    """(NUMA node, cpu ids, cpulist text) of a PCI device out of sysfs: <sysfs>/bus/pci/devices/<pci>/numa_node and
+    <sysfs>/devices/system/node/node<N>/cpulist ("0-31,64-95").  node < 0: the platform reports no affinity -> (node, None, None)."""
+    node = int(open(os.path.join(sysfs, "bus/pci/devices", pci.lower(), "numa_node")).read().strip())
+    if node < 0:
+        return node, None, None
+    cpus = open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read().strip()
+    ids = set()
+    for part in cpus.split(","):
+        lo, _, hi = part.partition("-")
+        ids.update(range(int(lo), int(hi or lo) + 1))
+    return node, ids, cpus
+
+
+def numa_pin(local_rank: int, enable: bool, dry: bool = False):
     """Pins this rank's host threads to the cores of the NUMA node its GPU hangs off (sysfs: /sys/class/drm/card*/device/numa_node through the
     device's PCI address; `rocm-smi --showtoponuma` shows the same).  One process per GPU otherwise floats over all sockets and its launch
-    latency depends on where the scheduler left it.  Returns a description for the bench line; never fails the run."""
+    latency depends on where the scheduler left it.  Returns a description for the bench line; never fails the run.
+    --dry-run (no GPU): the PCI address of rank i comes from GMPI_BENCH_PCI_IDS (comma separated) and the sysfs root from GMPI_BENCH_SYSFS -- the
+    lookup and the parsing run (tests/test_bench_ranks_gloo.py builds a fake tree for 8 ranks on 2 nodes), the affinity is reported, not applied."""
     if not enable:
         return None
     try:
-        pci = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
-        if pci is None:
-            import ctypes
-            buf = ctypes.create_string_buffer(64)
-            hip = ctypes.CDLL("libamdhip64.so")
-            if hip.hipDeviceGetPCIBusId(buf, 64, local_rank) != 0:
-                return "unavailable (hipDeviceGetPCIBusId failed)"
-            pci = buf.value.decode()
-        node_file = f"/sys/bus/pci/devices/{pci.lower()}/numa_node"
-        node = int(open(node_file).read().strip())
+        sysfs = os.environ.get("GMPI_BENCH_SYSFS", "/sys") if dry else "/sys"
+        if dry:
+            ids_env = [x for x in os.environ.get("GMPI_BENCH_PCI_IDS", "").split(",") if x]
+            if not ids_env:
+                return "unavailable (dry run without GMPI_BENCH_PCI_IDS)"
+            pci = ids_env[local_rank % len(ids_env)]
+        else:
+            pci = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
+            if pci is None:
+                import ctypes
+                buf = ctypes.create_string_buffer(64)
+                hip = ctypes.CDLL("libamdhip64.so")
+                if hip.hipDeviceGetPCIBusId(buf, 64, local_rank) != 0:
+                    return "unavailable (hipDeviceGetPCIBusId failed)"
+                pci = buf.value.decode()
+        node, ids, cpus = numa_cpus_of_pci(pci, sysfs)
         if node < 0:
             return f"gpu {local_rank} ({pci}): no NUMA affinity reported"
-        cpus = open(f"/sys/devices/system/node/node{node}/cpulist").read().strip()
-        ids = set()
-        for part in cpus.split(","):
-            lo, _, hi = part.partition("-")
-            ids.update(range(int(lo), int(hi or lo) + 1))
-        ids &= os.sched_getaffinity(0)
+        if not dry:
+            ids &= os.sched_getaffinity(0)
         if not ids:
             return f"gpu {local_rank} ({pci}): node {node} has no allowed cpu"
-        os.sched_setaffinity(0, ids)
+        if not dry:
+            os.sched_setaffinity(0, ids)
         return f"gpu {local_rank} ({pci}) -> NUMA node {node}, {len(ids)} cpus ({cpus})"
     except Exception as e:  # noqa: BLE001 -- a missing sysfs entry must not cost the bench line
         return f"unavailable ({type(e).__name__}: {e})"
@@ -609,12 +717,16 @@ class Workload:
 
 def companion_lines(a, dev, main_name):
     """Rank 0, N = 1, OUTSIDE the timed region: the configurations that otherwise have no driver-run witness -- config 3 with an fp32 volume (the
-    1024^2 x 96 variant whose kernel is memory-side bound), config 2 (BASELINE configs[1]), and config 3 in strict-order mode (the bit-identical
-    arithmetic the parity tests run).  Each: its own tensors, the same untimed clock ramp as the headline (--prewarm-ms), 5 warm-up + 20 launches
-    with a HIP-event pair around every launch on the launch stream, mean of the 20; frac = algorithmic bytes / mean / 8 TB/s; and the same
-    oracle comparison as the headline's `parity` block.  Not `value`; a witness."""
+    1024^2 x 96 variant whose kernel is memory-side bound), config 2 (BASELINE configs[1]), config 3 in strict-order mode (the bit-identical
+    arithmetic the parity tests run) and, since round 6, the per-GPU shards of BASELINE configs[3] (`cfg4_shard`: 8 camera-path views of ONE
+    512^2 x 96 MPI, render_video.py:95-130) and configs[4] (`cfg5_shard`: 4 seeds of 1024^2 x 256 with the transmittance output, 17 GB of
+    volumes generated in place) and the G-step's render at 1024^2 (`train1024`: forward, zero-fill, backward; train.py:740-779).  Each: its own
+    tensors, the same untimed clock ramp as the headline (--prewarm-ms), 5 warm-up + 20 launches with a HIP-event pair around every launch on the
+    launch stream, mean of the 20; frac = algorithmic bytes / mean / 8 TB/s, frac_footprint = the texel boxes the views touch / mean / 8 TB/s; and
+    the same oracle comparison as the headline's `parity` block.  Not `value`; a witness."""
     res = {}
-    for key, name, strict in (("cfg3_f32", "cfg3_f32", False), ("cfg2", "cfg2", False), ("cfg3_strict", "cfg3", True)):
+    for key, name, strict in (("cfg3_f32", "cfg3_f32", False), ("cfg2", "cfg2", False), ("cfg3_strict", "cfg3", True),
+                              ("cfg4_shard", "cfg4", False), ("cfg5_shard", "cfg5", False)):
         if name == main_name and not strict:
             continue
         try:
@@ -636,18 +748,41 @@ def companion_lines(a, dev, main_name):
                 w.r.mpi.raise_on_status(w.status)
                 ms = [e0.elapsed_time(e1) for e0, e1 in evs]
                 mean = sum(ms) / len(ms)
+                fbytes = footprint_bytes(w.ray, w.eye, w.dhw, w.S, w.s_in, w.want_T)
                 ent = dict(workload=w.desc + (", strict-order arithmetic" if strict else ""), ms=round(mean, 4), min_ms=round(min(ms), 4),
                            launches=len(ms), algorithmic_bytes_per_launch=w.abytes, frac=round(w.abytes / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           footprint_bytes_per_launch=fbytes, frac_footprint=round(fbytes / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                            mpix_planes_per_s=round(w.n_views * w.S * w.S * w.D / (mean * 1e-3) / 1e6, 1))
                 if not a.no_parity:
                     par = w.parity()
                     ent["parity_ok"] = par["ok"]
-                    ent["parity"] = {k: par[k] for k in ("strict_bit_exact", "max_abs_err_color", "max_abs_err_depth")}
+                    ent["parity"] = {k: par[k] for k in ("strict_bit_exact", "max_abs_err_color", "max_abs_err_depth", "max_abs_err_T")}
             res[key] = ent
             del w
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001 -- a companion must not cost the headline line
             res[key] = dict(error=f"{type(e).__name__}: {e}"[:300])
+    try:
+        tw = TrainWorkload("train1024", dev, 0, a.variant)
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < a.prewarm_ms:
+            tw.step()
+            torch.cuda.synchronize(dev)
+        parts = tw.parts()
+        step_ms = parts["forward_ms"] + parts["grad_zero_fill_ms"] + parts["backward_ms"]
+        ent = dict(workload=tw.desc + " (curriculums.py:89-91, train.py:740-779)", forward_ms=parts["forward_ms"], grad_zero_fill_ms=parts["grad_zero_fill_ms"],
+                   backward_ms=parts["backward_ms"], ms=round(step_ms, 4), forward_frac=parts["forward_frac"], backward_frac=parts["backward_frac"],
+                   algorithmic_bytes_per_launch=tw.ab_fwd + tw.ab_bwd, frac=round((tw.ab_fwd + tw.ab_bwd) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   what="forward | zero-fill | backward each alone: 20 launches behind 3 warm-ups, HIP events on the launch stream; ms = their sum")
+        if not a.no_parity:
+            par = tw.parity()
+            ent["parity_ok"] = par["ok"]
+            ent["parity"] = {k: par[k] for k in ("vs_all_atomic_kernel", "vs_reference_autograd", "bars")}
+        res["train1024"] = ent
+        del tw
+        torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        res["train1024"] = dict(error=f"{type(e).__name__}: {e}"[:300])
     return res
 
 
@@ -754,7 +889,7 @@ def main():
         if use_dist:
             dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    pinned = None if dry else numa_pin(local_rank, a.numa_pin)
+    pinned = numa_pin(local_rank, a.numa_pin, dry)
 
     import ml_gmpi_amd
     from ml_gmpi_amd import _lib
@@ -849,6 +984,31 @@ def main():
                 sync()
                 e2e_pre.append((time.perf_counter() - t1) * 1e3)
             e2e = dict(mean=sum(e2e_t) / len(e2e_t), max=max(e2e_t), b2b=e2e_b2b_ms, pre=sorted(e2e_pre)[len(e2e_pre) // 2])
+            # What `install()` hands the reference's scripts: range_check="full" = the reference's min/max over the WHOLE volume (mpi_renderer.py:447-449,
+            # mpi.py:185-187).  The exhaustive pass runs in the first call on a volume and again whenever the volume changed (hip_mpi.MPI._full_check_needed);
+            # the reference's video loop renders 100 views of one unchanged MPI.  `first`: a call that runs the pass; `mean`: 24 further calls.
+            r_full = ml_gmpi_amd.make_renderer(preset, n_planes=D, device=dev, kernel_variant=a.variant, strict_order=a.strict, on_out_of_plane="raise",
+                                               range_check="full")
+            r_full.set_cam(r_full.cam_fov, S, S)
+            for _ in range(40):                             # (a fresh renderer: its pose look-ahead's first batches stall a call for tens of ms once)
+                r_full.render(rgba, S, S, views_per_mpi=vpm)
+            full_first = []
+            for _ in range(3):
+                r_full.mpi._full_check_passed = None        # (as after an in-place update of the volume)
+                sync()
+                t1 = time.perf_counter()
+                r_full.render(rgba, S, S, views_per_mpi=vpm)
+                sync()
+                full_first.append((time.perf_counter() - t1) * 1e3)
+            full_t = []
+            for _ in range(24):
+                sync()
+                t1 = time.perf_counter()
+                r_full.render(rgba, S, S, views_per_mpi=vpm)
+                sync()
+                full_t.append((time.perf_counter() - t1) * 1e3)
+            e2e.update(full_first=sorted(full_first)[1], full_mean=sum(full_t) / len(full_t))
+            del r_full
         sweep = None
         if a.pose_draws > 0 and a.workload != "cfg4":  # (config 4's poses are a fixed yaw sweep, not a draw)
             sweep = pose_sweep(r, rgba, dhw, n_views, vpm, want_T, S, a.pose_draws, out, status)
@@ -873,6 +1033,10 @@ def main():
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)            # straggler visibility: every rank's own wall time per step
         per_rank = [float(x[0]) for x in allr]
+        if a.numa_pin:   # every rank's binding (the line is rank 0's)
+            pins = [None] * world
+            dist.all_gather_object(pins, pinned)
+            pinned = pins
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = float(t[0]), float(t[1])
 
@@ -956,11 +1120,17 @@ def main():
         }
         if e2e is not None:
             line.update({"e2e_render_ms": round(e2e["mean"], 3), "e2e_render_max_ms": round(e2e["max"], 3),
-                         "e2e_render_back_to_back_lagged_ms": round(e2e["b2b"], 3), "e2e_render_prefetched_poses_ms": round(e2e["pre"], 3)})
+                         "e2e_render_back_to_back_lagged_ms": round(e2e["b2b"], 3), "e2e_render_prefetched_poses_ms": round(e2e["pre"], 3),
+                         # range_check="full" (install()'s default = the reference's whole-volume assertion): a call that runs the exhaustive pass | the
+                         # calls on the unchanged volume that follow (the pass is skipped while the volume is provably unchanged)
+                         "e2e_render_install_default_first_ms": round(e2e["full_first"], 3), "e2e_render_install_default_ms": round(e2e["full_mean"], 3)})
         if use_dist:
             # the only collective of the job, and the spread of the ranks (the headline time is the max over ranks)
+            full_S = WORKLOADS[a.workload][1]
             line["rccl"] = {"world": dist.get_world_size(), "backend": dist.get_backend(), "gather_ms": round(gather_ms, 3),
                             "gather_bytes": gather_bytes, "gather_gbs": round(gather_bytes / (gather_ms * 1e-3) / 1e9, 2),
+                            # (SURVEY 8e's figure for the workload at its full size: world x views x channels x S^2 x 4 B -- equal to gather_bytes except in a --dry-run, whose images are shrunk)
+                            "gather_bytes_at_full_size": world * n_views * (4 + (1 if want_T else 0)) * full_S * full_S * 4,
                             "what": "one all_gather_into_tensor of the finished frames [world, views, channels, H, W] fp32, second call (the first sets the communicator up)"}
             line["ms_per_step_ranks"] = {"min": round(min(per_rank), 4), "max": round(max(per_rank), 4), "all": [round(x, 4) for x in per_rank]}
         if dry:

@@ -18,7 +18,8 @@
  *     (the reference's `sys.exit(1)` on a ray leaving the last plane, mpi.py:105-128, becomes a
  *     status bit the host turns into the same diagnostics);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
- *   - re-entrant, no global state.
+ *   - re-entrant; no global state that a result depends on (the only process-wide datum is an atomic launch counter that stamps the view
+ *     gate words of GMPI_VARIANT_AUTO's two-kernel launches, so that a workspace never needs clearing).
  */
 #ifndef GMPI_RENDER_H
 #define GMPI_RENDER_H
@@ -39,9 +40,18 @@ enum {
     GMPI_FLAG_ALIGN_CORNERS = 1 << 0,    /* MPI(align_corners=...)            mpi.py:157-159, 86-99    */
     GMPI_FLAG_OUT_PM1 = 1 << 1,          /* write 2*C-1 instead of C          mpi_renderer.py:467      */
     GMPI_FLAG_CHECK_LAST_PLANE = 1 << 2, /* assert_not_out_of_last_plane      mpi.py:381-395, 103-109  */
-    GMPI_FLAG_CHECK_RANGE = 1 << 3,      /* rgba/alpha in [0,1] on the texels the render touches
-                                            (mpi.py:185-187, mpi_renderer.py:447-449); the exhaustive
-                                            variant is gmpi_rgba_range_check_launch                   */
+    GMPI_FLAG_CHECK_RANGE = 1 << 3,      /* rgba/alpha in [0,1] (mpi.py:185-187, mpi_renderer.py:447-449) on AT LEAST the texels the render
+                                            SAMPLES (the taps with which some pixel forms its bilinear sample); a kernel may test more:
+                                              band kernel (GMPI_VARIANT_BAND, AUTO's large launches): exactly the sampled taps (the landed tap
+                                                registers are folded into a running maximum);
+                                              tile / strip kernels (LDS, WAVE): every texel of the boxes they stage -- the sampled taps plus
+                                                the 16-byte items and box rows around them;
+                                              gather kernel: exactly the sampled taps.
+                                            STATUS_RGBA_RANGE therefore never reports a texel in [0,1], always reports an out-of-range or
+                                            NaN texel that some pixel samples, and MAY miss one that no pixel samples (outside every view's
+                                            footprint: 10-16 % of a volume) -- which the reference, testing min/max of the whole tensor,
+                                            reports.  The exhaustive test is gmpi_rgba_range_check_launch (one streaming pass); the Python
+                                            host runs it with range_check="full" (install()'s default) once per unchanged volume.        */
     GMPI_FLAG_STRICT_ORDER = 1 << 4,     /* one rounding per reference op everywhere (bit-identical to
                                             oracle/mpi_oracle.c); default lets the blend use FMA       */
     GMPI_FLAG_HINT_FRONTAL = 1 << 5,     /* advisory: every view's camera axis (z_dir) is within 0.2 rad of the MPI normal (0,0,1).
@@ -58,7 +68,14 @@ enum {
                                             small launch ~18 us of table kernel and empty launches); launches of up to 512 strips stay with the
                                             strip kernel whatever the hint (its 6-way plane split still wins there).  Like
                                             GMPI_FLAG_HINT_FRONTAL it never changes a result.                                                */
-    GMPI_FLAG_ALL = (1 << 7) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
+    GMPI_FLAG_GRAD_ZEROED = 1 << 7,      /* gmpi_mpi_render_backward_launch only (round 6): the caller promises that grad_rgba holds ZEROS on
+                                            entry and is not accumulated into by anything else until the launch has finished.  The library may
+                                            then WRITE whole 128-byte lines of the gradient with plain stores where it can prove that a single
+                                            workgroup holds every contribution to them (one view per MPI, a volume whose rows, channels, planes and
+                                            MPIs start on 128-byte boundaries, a pinhole ray field -- see the backward's comment) instead of adding
+                                            them atomically: the result is the same, the launch is faster.  Without the flag the launch only
+                                            ever ADDS into grad_rgba (round 5's contract: several launches may accumulate into one buffer).     */
+    GMPI_FLAG_ALL = (1 << 8) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
 };
 
 /* bits of status[0] (OR-accumulated across launches until the caller clears the word) */
@@ -116,7 +133,11 @@ typedef struct GmpiRenderParams {
     int64_t rgba_stride[5];  /* element strides; [4] must be 1; 0 allowed on [0] (expand) */
     const int32_t *view_to_mpi; /* [N] or NULL                                          */
     const float *dhw;        /* [M, D, 3] (distance, height, width), contiguous         */
-    const float *ray_dir;    /* [N, 3, H, W] unit ray directions, contiguous            */
+    const float *ray_dir;    /* [N, 3, H, W] unit ray directions, contiguous.  The LDS-staged variants (LDS, WAVE, BAND and therefore AUTO)
+                                stage, per pixel tile and plane, the texel box spanned by the tile's four corner pixels: that contains every tap
+                                of the tile iff the field is a pinhole camera's (straight pixel lines map to straight lines on every plane), which
+                                is what Camera.generate_rays (camera.py:182-211) / gmpi_generate_rays_launch produce.  NaN / infinite rays are
+                                handled (NaN pixels, no false status bit); an arbitrary smooth field needs GMPI_VARIANT_GATHER.               */
     const float *eye_pos;    /* [N, 3]                                                  */
     const float *z_dir;      /* [N, 3] optical axis                                     */
 
@@ -153,7 +174,10 @@ int gmpi_mpi_render_launch(const GmpiRenderParams *params, void *stream);
  * pixel*plane), anything else the tile kernel that stages the scatter in LDS.  grad_rgb [N,3,H,W] is the gradient
  * w.r.t. the colour the forward wrote (the OUT_PM1 factor 2 is applied inside when that flag is set); grad_depth
  * [N,1,H,W] or NULL; grad_rgba [M,D,4,Ht,Wt] fp32 with the given element strides (innermost 1) is ACCUMULATED into
- * (atomicAdd) -- the caller zero-fills it.
+ * (atomicAdd) -- the caller zero-fills it.  With GMPI_FLAG_GRAD_ZEROED in params->flags (the caller has just zero-filled it and nothing else
+ * adds into it meanwhile) lines that one workgroup provably owns are written with plain stores instead.  `ray_dir` must be a pinhole ray field
+ * (straight pixel lines map to straight lines on every plane -- what `Camera.generate_rays` / gmpi_generate_rays_launch produce) for the tile
+ * kernels' texel boxes and for that ownership proof; GMPI_VARIANT_GATHER makes no such assumption.
  */
 int gmpi_mpi_render_backward_launch(const GmpiRenderParams *params, const float *grad_rgb, const float *grad_depth,
                                     float *grad_rgba, const int64_t *grad_rgba_stride, void *stream);

@@ -272,6 +272,7 @@ static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, 
     p.ws = q->workspace;
     p.ws_bytes = q->workspace != nullptr ? q->workspace_bytes : 0;
     p.gate = nullptr, p.gate_gen = 0, p.gate_sense = 0;
+    p.band_cols = 1;
     return GMPI_OK;
 }
 
@@ -280,8 +281,16 @@ static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, 
 // frontal hint says; at 128 bands it loses (0.122-0.133 against 0.078): profiles/r05_small_launches.txt.
 constexpr int64_t kAutoBandMin = 256;
 constexpr int64_t kAutoBandMinF32 = 1024;  // fp32: bands of 128 x 8 pixels (at 512 -- config 2 -- the strip kernel is as fast: profiles/r03_band_variants.txt)
+// The 256-band threshold was measured in DEFAULT mode with frontal-to-moderate cameras (profiles/r05_small_launches.txt).  Two kinds of 16-bit launches keep
+// rounds 3-4's threshold of 512 bands: strict-order launches (never measured below it: the strip kernel keeps its 2^18..2^19-pixel range) and launches whose
+// caller says that some camera is tilted beyond 0.53 rad (a view the band kernel cannot stage then costs a table kernel and an empty band launch on top).
+constexpr int64_t kAutoBandMinUnmeasured = 512;
 
 // does GMPI_VARIANT_AUTO consider the band kernel for this launch (given a workspace and the band kernel's alignment preconditions)?
+static int64_t band_count(const KParams& p, int dtype) {
+    const int bw = band_pixels_wide(dtype);
+    return static_cast<int64_t>(p.N) * ((p.W + bw - 1) / bw) * ((p.H + 7) / 8);
+}
 static bool auto_takes_band(const KParams& p, int dtype) {
     if (dtype != GMPI_DTYPE_BF16 && dtype != GMPI_DTYPE_F32 && dtype != GMPI_DTYPE_F16) return false;
     // Views that share one MPI (views_per_mpi > 1: the video paths) stay with the tile kernel: it interleaves them per tile so that the
@@ -293,7 +302,9 @@ static bool auto_takes_band(const KParams& p, int dtype) {
     // (an image that fills less than 3/4 of its bands -- narrower than a band, a ragged last column -- wastes the idle lanes' issue slots:
     //  the tile kernel's 32 x 16 tiles fit such images better)
     if (static_cast<int64_t>(p.W) * 4 < cols * bw * 3 || static_cast<int64_t>(p.H) * 4 < rows * 8 * 3) return false;
-    return static_cast<int64_t>(p.N) * cols * rows >= (dtype == GMPI_DTYPE_F32 ? kAutoBandMinF32 : kAutoBandMin);
+    int64_t need = dtype == GMPI_DTYPE_F32 ? kAutoBandMinF32 : kAutoBandMin;
+    if (dtype != GMPI_DTYPE_F32 && (p.flags & (GMPI_FLAG_STRICT_ORDER | GMPI_FLAG_HINT_TILTED)) != 0) need = kAutoBandMinUnmeasured;
+    return band_count(p, dtype) >= need;
 }
 
 static int hip_rc(hipError_t e) { return e == hipSuccess ? GMPI_OK : GMPI_E_LAUNCH - static_cast<int>(e); }
@@ -336,12 +347,10 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
         // (a launch the band kernel takes -- below -- is not "small", whatever the hints say: 16-bit volumes reach the band threshold at exactly the
         //  2048 strips up to which a frontal hint would pick the strip kernel)
-        bool band_path = lds_ok && auto_takes_band(p, params->rgba_dtype) && band_variant_supports(p, params->rgba_dtype);
-        // ... unless the launch is in the range round 5 added (16-bit volumes, 256-511 bands) and the caller says that some camera is tilted beyond
-        // 0.53 rad: a view the band kernel cannot stage goes to the tile kernel behind a table kernel and an empty band launch, ~18 us that such a small
-        // launch feels (two views of 512^2 at 0.45 rad of yaw: 0.158 ms against the tile kernel's 0.140; the frontal ones 0.120 against 0.143)
-        if (band_path && tilted && params->rgba_dtype != GMPI_DTYPE_F32 &&
-            static_cast<int64_t>(p.N) * ((p.W + 255) / 256) * ((p.H + 7) / 8) < 512) band_path = false;
+        // (auto_takes_band keeps 16-bit launches of 256-511 bands off the band path in strict-order mode and when the caller says that some camera is
+        //  tilted beyond 0.53 rad: a view the band kernel cannot stage goes to the tile kernel behind a table kernel and an empty band launch, ~18 us
+        //  that such a small launch feels -- two views of 512^2 at 0.45 rad of yaw: 0.158 ms against the tile kernel's 0.140; the frontal ones 0.120 against 0.143)
+        const bool band_path = lds_ok && auto_takes_band(p, params->rgba_dtype) && band_variant_supports(p, params->rgba_dtype);
         if (band_path) variant = GMPI_VARIANT_LDS;
         // Large launches over bf16 / fp32 volumes, when the caller lends a workspace: the band kernel (256 x 8 / 128 x 8 pixel bands, LDS-DMA;
         // 0.81 ms on BASELINE config 3 where the tile kernel takes 1.02, 1.21 against 1.33 with an fp32 volume) -- for the views it can stage.  Whether a view's texel boxes fit the band

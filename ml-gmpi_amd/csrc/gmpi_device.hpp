@@ -41,6 +41,7 @@ struct KParams {
     // Whatever the workspace held before, exactly one of the two kernels renders each view.  gate == nullptr: every view.
     uint32_t* gate;
     uint32_t gate_gen, gate_sense;
+    int32_t band_cols;  // band kernel: band columns per XCD window (render_band.hip band_pos; set by launch_band)
 };
 
 // blockIdx -> work item (pixel tile / band), "per view group" form: XCD x = blockIdx % 8 (workgroups are dealt round-robin to the 8 XCDs)

@@ -28,6 +28,7 @@
 #include "gmpi_device.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 
@@ -37,6 +38,12 @@ namespace band {
 constexpr int kNT = 1024;              // threads per workgroup (16 wavefronts)
 constexpr int SBW = 64, SBH = 8;       // sub-block: 64 x 8 pixels
 constexpr float kBoxEps = 1.0f / 64;
+// Band columns per XCD window (band_pos below), measured in round 6 (profiles/r06_band_order.txt: three boxes, alternating repeats, L2 -> fabric bytes
+// from FETCH_SIZE passes).  Two columns: config 3 (bf16) 0.7945 -> 0.7790 ms with 0.987 x instead of 1.074 x the algorithmic bytes crossing the L2s,
+// config 3 with an fp32 volume 1.170 -> 1.163 ms, 0.988 x instead of 1.081 x.  Deep fp32 stacks (config 5: 256 planes) are the exception: one column
+// is 1.5-4.6 % faster there although it moves more bytes (1.142 x against 1.079 x) -- not a channel or XCD imbalance (TCC_EA0_RDREQ / TCC_BUSY per
+// channel are flat to 0.1 % in every order), not the position in the run sequence, and box-dependent (one box of three shows no difference).
+constexpr int kWindowCols16 = 2, kWindowCols32 = 2, kWindowCols32Deep = 1, kDeepPlanes = 128;
 constexpr float kCoordLimit = 16384.0f;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -177,6 +184,21 @@ __device__ __forceinline__ void band_to_view(const KParams& p, int band_id, int 
     }
 }
 
+// band index inside the view -> (column, row) of bands.  The bands of a view are walked in WINDOWS of `wc` band columns: window by window, inside a
+// window row by row (the wc bands of a row next to each other).  XCD x = blockIdx % 8 owns a contiguous run of that walk (xcd_item_per_group), so
+// an XCD's share of a view is wc columns wide and the workgroups that are resident together in one L2 are neighbours in both directions.
+//   wc = 1: column-major (round 5): an XCD walks DOWN one column of bands -- vertical neighbours share 2-3 of their ~10 box rows;
+//   wc >= bands_x: row-major (rounds 3-4): horizontal neighbours share the partial 128-byte lines at every column border;
+//   in between: both (round 6; the table order x {ms, L2 -> fabric bytes} is in profiles/r06_band_order.txt).
+// No pixel's result depends on it (the strict-order tests compare every order against the same oracle).
+__device__ __forceinline__ void band_pos(int brem, int bands_x, int bands_y, int wc, int& bxi, int& byi) {
+    const int per_window = wc * bands_y;
+    const int g = brem / per_window, r = brem - g * per_window;
+    const int cols = min(wc, bands_x - g * wc);  // (the last window may be narrower)
+    byi = r / cols;
+    bxi = g * wc + (r - byi * cols);
+}
+
 // ---- the geometry table, written by a small kernel in front of the render kernel and read by the render kernel's waves through scalar loads
 //      (no LDS table, no table builds between the planes, no v_readfirstlane):
 //        recs[(band * D + plane) * NSB + sub-block] = uint4 { box origin address lo, hi | shape | gpart }          16 bytes
@@ -210,15 +232,8 @@ __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const
     const int band_id = blockIdx.x;
     int n, brem;
     band_to_view(p, band_id, bands_x * bands_y, n, brem);
-    // band index inside the view -> (column, row) of bands, COLUMN-major (round 5): an XCD's contiguous run of bands walks DOWN a column of
-    // bands, so the workgroups that run next to each other in time and on one XCD are vertical neighbours -- they share 2-3 of their ~10 box
-    // rows, horizontal neighbours 2 of ~130 box columns.  Against the row-major order of rounds 3-4, same box, two alternating repeats: config 5
-    // 3.29 / 3.35 -> 3.19 / 3.16 ms, config 3 fp32 1.208 / 1.238 -> 1.197 / 1.211, bf16 0.848 / 0.857 -> 0.845 / 0.838 (profiles/r05_band_order.txt).
-#ifdef GMPI_BAND_ROWMAJOR
-    const int byi = brem / bands_x, bxi = brem - byi * bands_x;
-#else
-    const int bxi = brem / bands_y, byi = brem - bxi * bands_y;
-#endif
+    int bxi, byi;
+    band_pos(brem, bands_x, bands_y, p.band_cols, bxi, byi);
     uint32_t ignore = 0;
     const int m = view_mpi(p, n, ignore);
     const int Ht = p.Ht, Wt = p.Wt, H = p.H, W = p.W;
@@ -299,6 +314,11 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     constexpr bool BF = kES == 2;                              // 16-bit texels (bf16 or fp16): the two-pixel geometry, taps by ds_read_u16_d16_hi
     constexpr bool F16 = std::is_same<TexT, f16_t>::value;     // fp16: the loaded half is the value's fp16 pattern -- converted inside the FMA (v_fma_mix_f32)
 
+    // `smem` is the ONLY __shared__ object of this kernel, i.e. it starts at LDS offset 0, and the staging buffers lead it: the [0,1] test below folds
+    // every tap REGISTER, so every tap must read staged texels (or nothing).  A NaN coordinate saturates to LDS address 0 = the head of buffer 0
+    // (texels: every box has >= 2 rows and >= 1 item, and buffer 0 holds a landed or landing plane at every step); an address past the allocation reads
+    // zeros; addresses in between are in-box by the corner argument, which needs a pinhole ray field (include/gmpi_render.h).
+    // tests/test_hip_band.py::test_band_range_check_has_no_false_alarm_on_nan_and_huge_rays.
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::kLdsBytes];
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const uint32_t tile_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte*)smem));  // the staging buffers lead the allocation (see coords(): a NaN coordinate reads THEM)
@@ -314,15 +334,8 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     int n, brem;
     band_to_view(p, band_id, bands_x * bands_y, n, brem);
     if (view_gated_out(p, n)) return;  // (AUTO: a view with a box that does not fit is the tile kernel's)
-    // band index inside the view -> (column, row) of bands, COLUMN-major (round 5): an XCD's contiguous run of bands walks DOWN a column of
-    // bands, so the workgroups that run next to each other in time and on one XCD are vertical neighbours -- they share 2-3 of their ~10 box
-    // rows, horizontal neighbours 2 of ~130 box columns.  Against the row-major order of rounds 3-4, same box, two alternating repeats: config 5
-    // 3.29 / 3.35 -> 3.19 / 3.16 ms, config 3 fp32 1.208 / 1.238 -> 1.197 / 1.211, bf16 0.848 / 0.857 -> 0.845 / 0.838 (profiles/r05_band_order.txt).
-#ifdef GMPI_BAND_ROWMAJOR
-    const int byi = brem / bands_x, bxi = brem - byi * bands_x;
-#else
-    const int bxi = brem / bands_y, byi = brem - bxi * bands_y;
-#endif
+    int bxi, byi;
+    band_pos(brem, bands_x, bands_y, p.band_cols, bxi, byi);
 
     const int tid = threadIdx.x;
     // Registers are the scarce resource (64 per lane for 8 waves per SIMD): values that only depend on the thread index are
@@ -540,10 +553,14 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
                 const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
                 c.nw = wx0 * wy0, c.ne = wx1 * wy0, c.sw = wx0 * wy1, c.se = wx1 * wy1;
             }
-            // LDS byte address of the north-west tap of channel 0: two exact fp32 FMAs and one saturating conversion (NaN -> 0: the head of
-            // the staging buffers, i.e. texels; an address past the allocation reads zeros): the box contains every tap of the sub-block (corner argument)
+            // LDS byte address of the north-west tap of channel 0: two exact fp32 FMAs and one saturating conversion: the box contains every tap of the
+            // sub-block (corner argument).  The conversion is the SIGNED one (round 6): NaN -> 0 (the head of the staging buffers, i.e. texels), +inf /
+            // huge -> 0x7fffffff and -inf -> 0x80000000, both far past the allocation even with the taps' immediate offsets added (such reads return
+            // zeros) -- the unsigned conversion saturated +inf to 0xffffffff, which the offsets wrapped around to the bottom of LDS: an infinite ray
+            // component read whatever lay there, and the range check below, which folds every tap register, raised a false "alpha out of [0, 1]"
+            // (tests/test_hip_band.py::test_band_range_check_has_no_false_alarm_on_nan_and_huge_rays).  In-range addresses (< 2^24) are the same.
             const float af = __builtin_fmaf(fy, static_cast<float>(kRowBytes), __builtin_fmaf(fx, static_cast<float>(kES), rg.y));
-            c.a_tap = static_cast<uint32_t>(af);
+            c.a_tap = static_cast<uint32_t>(static_cast<int32_t>(af));
         };
         // The 16 taps of a pixel are fetched as two halves (channels R, G | B, A): 8 tap registers instead of 16 -- what lets two pixels per
         // thread live in 64 VGPRs without a spill reload in the plane loop (a scratch load shares vmcnt with the DMA: it would drain it).
@@ -933,8 +950,11 @@ bool band_variant_supports(const KParams& p, int dtype) {
 
 hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
-#ifdef GMPI_TUNE  // profiling builds: tune bits 8-9 = ablations (no memory traffic / no compositing)
+    p.band_cols = dtype != 0 ? band::kWindowCols16 : p.D > band::kDeepPlanes ? band::kWindowCols32Deep : band::kWindowCols32;
+#ifdef GMPI_TUNE  // profiling builds: tune bits 8-9 = ablations (no memory traffic / no compositing); GMPI_TUNE_ORDER = band columns per XCD window
     p.flags |= static_cast<uint32_t>((tune >> 8) & 127) << 16;
+    static const int env_order = [] { const char* e = getenv("GMPI_TUNE_ORDER"); return e ? atoi(e) : 0; }();
+    if (env_order > 0) p.band_cols = env_order;
 #else
     (void)tune;
 #endif

@@ -16,6 +16,7 @@ import contextlib
 import ctypes
 import sys
 import threading
+import weakref
 from typing import List, Optional, Sequence, Union
 
 import numpy as np
@@ -90,10 +91,10 @@ def _workspace(dev: torch.device, stream: int, need: int) -> torch.Tensor:
     key = _stream_key(dev, stream)
     ws = _lru_get(_WORKSPACES, key, lambda: torch.empty(need, dtype=torch.uint8, device=dev))  # (the caching allocator hands out 512-byte aligned blocks)
     if ws.numel() < need:
-        _retire_evicted(key, ws)   # (an earlier, smaller launch on this stream may still be using it)
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        with _CACHE_LOCK:
-            _WORKSPACES[key] = ws
+        bigger = torch.empty(need, dtype=torch.uint8, device=dev)
+        with _CACHE_LOCK:   # (the graveyard's prune-and-append is not atomic by itself: always under the cache lock, as in _lru_get)
+            _retire_evicted(key, ws)   # (an earlier, smaller launch on this stream may still be using it)
+            _WORKSPACES[key] = ws = bigger
     return ws
 
 
@@ -231,6 +232,19 @@ def _flush_at_exit() -> None:
         if not isinstance(e, SystemExit):
             traceback.print_exception(type(e), e, e.__traceback__)
         print("ml_gmpi_amd: a render with a lagged status check asserted (above); exit status 1", file=sys.stderr)
+        # os._exit skips every exit handler registered BEFORE this module was imported (atexit runs last-in first-out: logging.shutdown, the
+        # host program's own file writers ...) and the interpreter's flush of open files.  So: run what is still registered, close the logging
+        # handlers, flush the standard streams -- then leave with the status Python would not set by itself.
+        try:
+            atexit.unregister(_flush_at_exit)
+            atexit._run_exitfuncs()        # the handlers that would have run after this one
+        except BaseException:  # noqa: BLE001 -- a failing handler of the host program must not eat the exit status
+            traceback.print_exc()
+        try:
+            import logging
+            logging.shutdown()
+        except BaseException:  # noqa: BLE001
+            pass
         sys.stderr.flush(), sys.stdout.flush()
         os._exit(1)
 
@@ -290,6 +304,41 @@ class MPI(nn.Module):
         self.strict_order = strict_order
         self.range_check = range_check
         self.on_out_of_plane = on_out_of_plane
+        self._full_check_passed = None   # (weakref to the volume's base tensor, fingerprint): see _volume_fingerprint
+
+    # -- range_check="full": the exhaustive pass is skipped while the volume that passed it last is provably unchanged ------------------
+    # The reference asserts min/max over the WHOLE volume in every call (mpi_renderer.py:447-449, mpi.py:185-187); its video loop
+    # (render_video.py:95-130) renders 100 views of ONE unchanged MPI and would pay that streaming pass 100 times (0.54 ms per 3.2 GB against
+    # 0.2 ms per view).  A volume is "the one that passed" when it is the same Python tensor (or a view of the same base tensor -- `mpi[:1]`
+    # makes a new view object per call; the base's identity is held by a weak reference, so a NEW tensor the caching allocator places at the
+    # old address does not match), with the same pointer, shape, strides, dtype, and the same autograd version counter (bumped by every
+    # in-place operation on the tensor or any of its views -- the mechanism autograd itself relies on, tests/test_hip_backward.py; writes that
+    # bypass it -- `.data`, raw pointers -- are not seen, as autograd does not see them).  Only a call that has READ its status words back and
+    # found them clean records a pass (the default, status_mode="sync"); deferred and lagged calls always run the pass.  The per-launch test
+    # of the sampled texels (GMPI_FLAG_CHECK_RANGE) is not affected: it stays in every launch.
+    def __getstate__(self):   # (torch.save / multiprocessing copies of a module: the weak reference does not pickle, and means nothing elsewhere)
+        state = self.__dict__.copy()
+        state["_full_check_passed"] = None
+        return state
+
+    @staticmethod
+    def _volume_fingerprint(rgba: torch.Tensor):
+        anchor = rgba._base if rgba._base is not None else rgba
+        return anchor, (rgba.data_ptr(), tuple(rgba.shape), tuple(rgba.stride()), rgba.dtype, rgba._version, str(rgba.device))
+
+    def _full_check_needed(self, rgba: torch.Tensor) -> bool:
+        hit = self._full_check_passed
+        if hit is None:
+            return True
+        anchor, fp = self._volume_fingerprint(rgba)
+        return not (hit[0]() is anchor and hit[1] == fp)
+
+    def _full_check_record(self, rgba: torch.Tensor) -> None:
+        anchor, fp = self._volume_fingerprint(rgba)
+        try:
+            self._full_check_passed = (weakref.ref(anchor), fp)
+        except TypeError:   # (a tensor subclass without weak references: no caching)
+            self._full_check_passed = None
 
     # -- host-side shape checks (mpi.py:161-216); the alpha range part happens on the device -----------
     def check_shapes(self, *, batch_rgba, batch_dhw, batch_ray_dir, batch_eye_pos, batch_z_dir, separate_background):
@@ -369,6 +418,7 @@ class MPI(nn.Module):
             raise _lib.GmpiError("MPI.forward needs tensors on a ROCm device: this package has no CPU path "
                                  f"(got rgba on {rgba.device})")
         dev = rgba.device
+        rgba_in = rgba   # (as the caller passed it: the identity the full-range-check cache is keyed on)
         if rgba.dtype not in _DTYPES:
             rgba = rgba.float()
         if rgba.stride(4) != 1 or any(s < 0 for s in rgba.stride()):
@@ -462,10 +512,12 @@ class MPI(nn.Module):
                     ws = _workspace(dev, stream, need)
                     p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
             with _on_device(dev if on_device else None):
-                if self.range_check == "full":
+                ran_full = False
+                if self.range_check == "full" and self._full_check_needed(rgba_in):
                     vol = rgba if rgba.is_contiguous() else rgba.contiguous()
                     _lib.check(lib.gmpi_rgba_range_check_launch(vol.data_ptr(), p.rgba_dtype, vol.numel(),
                                                                 status.data_ptr(), stream), "gmpi_rgba_range_check_launch")
+                    ran_full = True
                 _lib.check(lib.gmpi_mpi_render_launch(ctypes.byref(p), stream), "gmpi_mpi_render_launch")
             res = dict(color=color, depth=depth, T=T, status=status)
             if _in_autograd_fn:  # what the backward needs to rebuild the launch
@@ -483,7 +535,10 @@ class MPI(nn.Module):
                     # (also a KeyboardInterrupt between the launch and the read-back: the shared words must not keep bits for the next call)
                     if status.is_cuda:
                         status.zero_()
+                    self._full_check_passed = None
                     raise
+                if ran_full:
+                    self._full_check_record(rgba_in)   # (read back and clean: the whole volume is in [0, 1])
             return res
 
     # -- status word -> the reference's assertion behaviour ------------------------------------------------------
@@ -582,6 +637,7 @@ class _RenderFunction(torch.autograd.Function):
         p.rgb_out = p.depth_out = p.status = None
         p.transmittance_out = T.data_ptr()
         grad = torch.zeros(ctx.in_shape, dtype=torch.float32, device=dev)
+        p.flags |= _lib.FLAG_GRAD_ZEROED   # (fresh zeros, nobody else adds into them: the launch may store the lines a workgroup owns)
         if g_color is None:
             g_color = torch.zeros((p.N, 3, p.H, p.W), dtype=torch.float32, device=dev)
         g_color = g_color.to(torch.float32).contiguous()

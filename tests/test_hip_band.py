@@ -96,6 +96,33 @@ def test_band_range_check_fp16():
     assert int(out["status"][0]) == 0 and np.array_equal(out["color"], oracle.render(nz.float(), dhw, ray, eye, zd)["color"])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_band_range_check_has_no_false_alarm_on_nan_and_huge_rays(dtype):
+    """The [0,1] test folds every TAP REGISTER (render_band.hip tap_fold8), so a tap that reads something else than staged texels would raise a false
+    "alpha out of [0, 1]".  Rays the coordinate chain turns into NaN tap addresses (the conversion saturates NaN to LDS address 0: the head of the
+    staging buffers, always texels) or into addresses past the allocation (reads zeros) must leave the status clean -- behind a launch of ANOTHER kernel
+    that left arbitrary bytes in LDS -- and must not disturb the other pixels (bit for bit in strict mode).  check_last_plane is off: such rays leave the
+    last plane by definition."""
+    rgba, dhw, ray, eye, zd = _random_case(seed=77, B=2, D=6, S=256)
+    vol = rgba.to(dtype)
+    clean = hip_render(vol, dhw, ray, eye, zd, variant="band", strict=True, check_last=False)
+    bad = ray.clone()
+    bad[0, :, 40:43, 100:170] = float("nan")          # NaN rays: a strip inside one band
+    bad[1, 0, 200, 7] = float("inf")                  # x component infinite
+    bad[1, :, 13, 250] = torch.tensor([3e30, -3e30, 1e-30])   # finite, absurd: coordinates beyond +-16384 -> the band's boxes are marked unfit (gather path)
+    junk = torch.randn(1 << 22, device="cuda:0")
+    for strict in (True, False):
+        torch.sort(junk)                               # (a library kernel that uses LDS for its own data runs on every CU in front of the render)
+        out = hip_render(vol, dhw, bad, eye, zd, variant="band", strict=strict, check_last=False)
+        assert int(out["status"][0]) == 0, (strict, out["status"][:4])
+        if strict:
+            ok = np.ones(clean["color"].shape[-2:], dtype=bool)
+            for n, ys, xs in ((0, slice(40, 43), slice(100, 170)), (1, slice(200, 201), slice(7, 8)), (1, slice(13, 14), slice(250, 251))):
+                m = ok.copy(); m[ys, xs] = False
+                for k in ("color", "depth", "T"):
+                    assert np.array_equal(out[k][n][:, m], clean[k][n][:, m]), (n, k)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
 def test_band_range_check_sees_every_sampled_texel(dtype):
     """The band kernel's [0,1] test runs on the taps (late round 5: a running maximum over the tap registers instead of an LDS read-back of the

@@ -212,7 +212,9 @@ def test_reference_generate_img_drives_the_installed_renderer(monkeypatch):
     assert gen_calls == [D, D]                                        # the whole-volume call and the one chunk (:42-75)
     renders = [c for c in rec.calls if c[0] == "render"]
     assert len(renders) == len(angles) and len(imgs) == len(angles) == len(depths) == len(tensors)
-    assert [c[0] for c in rec.calls] == ["range_check", "render"] * len(angles)   # install(): the reference's whole-volume assertion
+    # install(): the reference's whole-volume assertion (mpi_renderer.py:447-449) -- ONCE for the loop's one unchanged volume (round 6; rounds 1-5 paid the
+    # exhaustive pass in front of every one of the path's views: tests/test_range_check_cache.py)
+    assert [c[0] for c in rec.calls] == ["range_check", "render"] + ["render"] * (len(angles) - 1)
     for (_, p, eye), yaw in zip(renders, angles):
         assert (p.N, p.M, p.D, p.Ht, p.Wt, p.H, p.W) == (1, 1, D, T, T, S, S)
         assert p.flags & _lib.FLAG_OUT_PM1 and p.flags & _lib.FLAG_CHECK_LAST_PLANE and p.variant == _lib.VARIANT_AUTO

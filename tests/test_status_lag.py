@@ -162,8 +162,13 @@ def test_lagged_assertion_at_exit_is_exit_status_1(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    early, logf = str(tmp_path / "early.txt"), str(tmp_path / "host.log")
     code = (
-        "import sys, torch\n"
+        "import atexit, logging, sys, torch\n"
+        # a host program's own exit handler and log file, registered BEFORE this package is imported: they must still run / be flushed
+        f"atexit.register(lambda: open({early!r}, 'w').write('written by an exit handler registered before the import'))\n"
+        f"logging.basicConfig(filename={logf!r}, level=logging.INFO)\n"
+        "logging.getLogger('host').info('host log line')\n"
         f"sys.path.insert(0, {root!r})\n"
         "import ml_gmpi_amd\n"
         "dev = torch.device('cuda:0')\n"
@@ -177,3 +182,5 @@ def test_lagged_assertion_at_exit_is_exit_status_1(tmp_path):
     assert "script end" in res.stdout
     assert res.returncode == 1, (res.returncode, res.stderr[-500:])
     assert "alpha to be within" in res.stderr
+    assert open(early).read().startswith("written by an exit handler")      # (os._exit would have skipped it)
+    assert "host log line" in open(logf).read()

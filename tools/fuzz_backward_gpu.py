@@ -45,6 +45,10 @@ for i in range(n_cases):
     D = int(rng.choice([1, 2, 5, 9, 32, 97, 120])) if not big else int(rng.choice([2, 5, 12]))
     M = int(rng.integers(1, 4))
     mode = rng.integers(0, 3)
+    if rng.random() < 0.5:   # round 6: the flush STORES whole aligned 128-byte lines that are one tile's alone -- needs Wt % 32 == 0 and one view per MPI
+        Wt = 32 * int(rng.integers(1, 12 if big else 4))
+        if rng.random() < 0.7:
+            mode = 0
     if mode == 0:
         vpm, v2m, N = 1, None, M
     elif mode == 1:

@@ -66,3 +66,12 @@ for S, n in ((256, 8), (512, 2)):
     for yaw in (0.0, 0.3, 0.45, 0.578):
         gy = torch.full((n, 1), yaw); gp = torch.zeros((n, 1))
         dump(f"p{S}_y{int(round(yaw * 1000)):03d}", r.sample_cam_poses(n, 0, 0, 0, 0, False, given_yaws=gy, given_pitches=gp))
+
+# round 6 (band order against the plane count): the FFHQ preset with 256 planes under bench.py's pose draw
+kw = dict(PRESETS["FFHQ"])
+kw.update(n_mpi_planes=256, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse", cam_sample_method="truncated_gaussian",
+          mpi_align_corners=True, use_confined_volume=True, device=torch.device("cpu"))
+r = MPIRenderer(**kw)
+r.set_cam(r.cam_fov, 1024, 1024)
+torch.manual_seed(3)
+dump("b256", r.sample_cam_poses(4, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))

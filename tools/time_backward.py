@@ -35,6 +35,7 @@ for S, B in ((256, 8), (512, 4), (1024, 4)):
                              defer_status=True, _in_autograd_fn=True)
     p, keep = res["_bwd"]
     p.rgb_out = p.depth_out = None
+    p.flags |= _lib.FLAG_GRAD_ZEROED   # (what the autograd bridge passes: it has just zero-filled the gradient volume)
     prof = torch.zeros(64, dtype=torch.int32, device=dev)
     p.status = prof.data_ptr() if os.environ.get("GMPI_PROF_WORDS") else None
     grad = torch.zeros_like(vol)
