@@ -317,8 +317,13 @@ class TrainWorkload:
                     mpi.variant = was
             pstruct, keep = fwd()["_bwd"]
             pstruct.rgb_out = pstruct.depth_out = pstruct.status = None
-            pstruct.flags |= _lib.FLAG_GRAD_ZEROED   # (what the autograd bridge passes: every step zero-fills the gradient volume first)
             grad = torch.zeros_like(vol)
+            # what the autograd bridge does: MPI(backward="gather") lends the atomics-free pair its scratch (then no zero-fill); the default adds atomically
+            need = int(lib.gmpi_render_backward_workspace_bytes(ctypes.byref(pstruct))) if self.r.mpi.backward == "gather" else 0
+            bws = torch.empty(need, dtype=torch.uint8, device=dev) if need else None
+            if bws is not None:
+                pstruct.workspace, pstruct.workspace_bytes = bws.data_ptr(), bws.numel()
+                pstruct.flags |= _lib.FLAG_GRAD_OVERWRITE
             gstride = (ctypes.c_int64 * 5)(*grad.stride())
             cs = torch.cuda.current_stream(dev).cuda_stream
 
@@ -331,7 +336,7 @@ class TrainWorkload:
                                "gmpi_mpi_render_backward_launch")
                 finally:
                     pstruct.variant = was
-            self._abi = dict(fwd=fwd, bwd=bwd, grad=grad, status=status, keep=keep, pstruct=pstruct)
+            self._abi = dict(fwd=fwd, bwd=bwd, grad=grad, status=status, keep=keep, pstruct=pstruct, bwd_workspace=bws, needs_zero_fill=bws is None)
         return self._abi
 
     def parts(self, n=20):

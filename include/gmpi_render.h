@@ -68,13 +68,11 @@ enum {
                                             small launch ~18 us of table kernel and empty launches); launches of up to 512 strips stay with the
                                             strip kernel whatever the hint (its 6-way plane split still wins there).  Like
                                             GMPI_FLAG_HINT_FRONTAL it never changes a result.                                                */
-    GMPI_FLAG_GRAD_ZEROED = 1 << 7,      /* gmpi_mpi_render_backward_launch only (round 6): the caller promises that grad_rgba holds ZEROS on
-                                            entry and is not accumulated into by anything else until the launch has finished.  The library may
-                                            then WRITE whole 128-byte lines of the gradient with plain stores where it can prove that a single
-                                            workgroup holds every contribution to them (one view per MPI, a volume whose rows, channels, planes and
-                                            MPIs start on 128-byte boundaries, a pinhole ray field -- see the backward's comment) instead of adding
-                                            them atomically: the result is the same, the launch is faster.  Without the flag the launch only
-                                            ever ADDS into grad_rgba (round 5's contract: several launches may accumulate into one buffer).     */
+    GMPI_FLAG_GRAD_OVERWRITE = 1 << 7,   /* gmpi_mpi_render_backward_launch only (round 6): the caller does not need what grad_rgba holds.
+                                            With the workspace gmpi_render_backward_workspace_bytes asks for, the launch then WRITES every element
+                                            of grad_rgba (no zero-fill needed); without the flag it reads, adds and writes back.  On the tile-kernel
+                                            path (no workspace, or a launch the gather path does not take) the flag changes nothing: that path only
+                                            ever ADDS, and the caller zero-fills as before.                                                      */
     GMPI_FLAG_ALL = (1 << 8) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
 };
 
@@ -174,13 +172,19 @@ int gmpi_mpi_render_launch(const GmpiRenderParams *params, void *stream);
  * pixel*plane), anything else the tile kernel that stages the scatter in LDS.  grad_rgb [N,3,H,W] is the gradient
  * w.r.t. the colour the forward wrote (the OUT_PM1 factor 2 is applied inside when that flag is set); grad_depth
  * [N,1,H,W] or NULL; grad_rgba [M,D,4,Ht,Wt] fp32 with the given element strides (innermost 1) is ACCUMULATED into
- * (atomicAdd) -- the caller zero-fills it.  With GMPI_FLAG_GRAD_ZEROED in params->flags (the caller has just zero-filled it and nothing else
- * adds into it meanwhile) lines that one workgroup provably owns are written with plain stores instead.  `ray_dir` must be a pinhole ray field
- * (straight pixel lines map to straight lines on every plane -- what `Camera.generate_rays` / gmpi_generate_rays_launch produce) for the tile
- * kernels' texel boxes and for that ownership proof; GMPI_VARIANT_GATHER makes no such assumption.
+ * (atomicAdd) -- the caller zero-fills it.
+ * Round 6: when params->workspace holds at least gmpi_render_backward_workspace_bytes(params) bytes (256-byte aligned; N D H W 16 bytes for the
+ * sample gradients of every pixel and plane), the launch runs WITHOUT atomics: a pixel pass writes the sample gradients, a texel pass gathers them
+ * through each plane's homography and writes every cell of grad_rgba once (deterministic; += without GMPI_FLAG_GRAD_OVERWRITE, = with it: then no
+ * zero-fill is needed).  align_corners = True, uniform views_per_mpi (no view_to_mpi); other launches take the tile kernels whatever the workspace.
+ * `ray_dir` must be a pinhole ray field (straight pixel lines map to straight lines on every plane -- what `Camera.generate_rays` /
+ * gmpi_generate_rays_launch produce) for the tile kernels' texel boxes and for the gather's candidate windows; GMPI_VARIANT_GATHER (one pixel per lane,
+ * 16 atomics per pixel and plane: the cross-check) makes no such assumption and takes no workspace.
  */
 int gmpi_mpi_render_backward_launch(const GmpiRenderParams *params, const float *grad_rgb, const float *grad_depth,
                                     float *grad_rgba, const int64_t *grad_rgba_stride, void *stream);
+/* Bytes of caller-owned scratch with which the backward runs without atomics (0: this launch takes the tile kernels). */
+uint64_t gmpi_render_backward_workspace_bytes(const GmpiRenderParams *params);
 
 /*
  * Diagnostics for a tripped GMPI_STATUS_OUT_OF_LAST_PLANE: min_u, max_u, min_v, max_v of the

@@ -15,7 +15,7 @@ _LIB = None
 ABI_VERSION = 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 FLAG_ALIGN_CORNERS, FLAG_OUT_PM1, FLAG_CHECK_LAST_PLANE, FLAG_CHECK_RANGE, FLAG_STRICT_ORDER, FLAG_HINT_FRONTAL, FLAG_HINT_TILTED = 1, 2, 4, 8, 16, 32, 64
-FLAG_GRAD_ZEROED = 128   # backward only: grad_rgba holds zeros on entry (the library may store owned lines instead of adding)
+FLAG_GRAD_OVERWRITE = 128   # backward only: grad_rgba's content is not needed (with the backward's workspace every element is written: no zero-fill)
 STATUS_OUT_OF_LAST_PLANE, STATUS_RGBA_RANGE, STATUS_CAMERA_BEHIND_PLANE, STATUS_BAD_VIEW_INDEX = 1, 2, 4, 8
 STATUS_WORDS = 4
 VARIANT_AUTO, VARIANT_GATHER, VARIANT_LDS, VARIANT_WAVE, VARIANT_DMA, VARIANT_BAND = 0, 1, 2, 3, 4, 5
@@ -24,6 +24,7 @@ VARIANTS = {"auto": VARIANT_AUTO, "gather": VARIANT_GATHER, "lds": VARIANT_LDS, 
 EXPORTS = (
     "gmpi_mpi_render_launch",
     "gmpi_render_workspace_bytes",
+    "gmpi_render_backward_workspace_bytes",
     "gmpi_mpi_render_backward_launch",
     "gmpi_last_plane_uv_minmax_launch",
     "gmpi_rgba_range_check_launch",
@@ -154,6 +155,8 @@ def load_library():
     lib.gmpi_mpi_render_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp]
     lib.gmpi_render_workspace_bytes.restype = ctypes.c_uint64
     lib.gmpi_render_workspace_bytes.argtypes = [ctypes.POINTER(GmpiRenderParams)]
+    lib.gmpi_render_backward_workspace_bytes.restype = ctypes.c_uint64
+    lib.gmpi_render_backward_workspace_bytes.argtypes = [ctypes.POINTER(GmpiRenderParams)]
     lib.gmpi_mpi_render_backward_launch.restype = ctypes.c_int
     lib.gmpi_mpi_render_backward_launch.argtypes = [ctypes.POINTER(GmpiRenderParams), vp, vp, vp,
                                                     ctypes.POINTER(ctypes.c_int64), vp]

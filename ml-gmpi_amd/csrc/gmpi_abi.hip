@@ -22,6 +22,7 @@ bool band_variant_supports(const KParams& p, int dtype);                    // r
 uint64_t band_workspace_bytes(const KParams& p, int dtype);                 // render_band.hip
 uint32_t* band_gate_words(const KParams& p, int dtype);                     // render_band.hip
 int band_pixels_wide(int dtype);                                            // render_band.hip
+uint64_t backward_gather_workspace_bytes(const KParams& p);                 // render_backward_gather.hip
 
 // ---- min/max of the normalised grid on the last plane (mpi.py:103-109 diagnostics) --------------
 template <bool AC>
@@ -402,6 +403,13 @@ uint64_t gmpi_render_workspace_bytes(const GmpiRenderParams* params) {
     return 0;
 }
 
+uint64_t gmpi_render_backward_workspace_bytes(const GmpiRenderParams* params) {
+    KParams p;
+    if (to_kparams(params, p, false, true) != GMPI_OK || p.N == 0) return 0;
+    if (params->variant == GMPI_VARIANT_GATHER) return 0;   // the all-atomic cross-check kernel
+    return backward_gather_workspace_bytes(p);
+}
+
 int gmpi_mpi_render_backward_launch(const GmpiRenderParams* params, const float* grad_rgb, const float* grad_depth,
                                     float* grad_rgba, const int64_t* grad_rgba_stride, void* stream) {
     if (params != nullptr && params->struct_size == sizeof(GmpiRenderParams) && params->N == 0) return GMPI_OK;
@@ -531,6 +539,7 @@ int gmpi_query(int32_t what) {
         case 8: return 1;  // GMPI_VARIANT_BAND is built in
         case 9: return static_cast<int>(kAutoBandMin);
         case 10: return static_cast<int>(kAutoBandMinF32);
+        case 11: return 1;  // the atomics-free backward (pixel pass + texel gather) is built in
         default: return -1;
     }
 }

@@ -17,55 +17,12 @@
 // channel front to back to rebuild it in that representation.
 // Taps come straight from global memory (same addressing as the gather kernel): the backward runs at training sizes
 // (D = 32, gmpi.yml:78).  The coordinate chain is the forward's (plane_coord), so both sample the same texels.
-#include "gmpi_device.hpp"
+#include "gmpi_backward.hpp"
 
 #include <cstdlib>
 #include <type_traits>
 
 namespace gmpi {
-
-struct BwdParams {
-    const float* g_rgb;    // [N,3,H,W] gradient w.r.t. the colour the forward wrote ([0,1] or, with OUT_PM1, [-1,1])
-    const float* g_depth;  // [N,1,H,W] or nullptr
-    float* g_rgba;         // [M,D,4,Ht,Wt] fp32, accumulated into (caller zero-fills)
-    int64_t gs_mpi, gs_plane, gs_chan, gs_row;
-    int32_t own;           // tile kernel, round 6: whole 128-byte lines no other tile or view can touch may be STORED (launch_backward_t decides)
-};
-
-// transmittance as mantissa (in [0.5,1)) x 2^exponent
-struct XT {
-    float m;
-    int e;
-    __device__ __forceinline__ void renorm() {
-        e += __builtin_amdgcn_frexp_expf(m);
-        m = __builtin_amdgcn_frexp_mantf(m);
-    }
-    __device__ __forceinline__ float value() const { return __builtin_amdgcn_ldexpf(m, e); }
-};
-
-// Final transmittance of one pixel: the forward's value when it is usable, else a front-to-back walk of the alpha
-// channel in the extended representation.
-template <typename TexT, bool AC>
-__device__ __forceinline__ XT total_transmittance(const KParams& p, const float* __restrict__ dhw, const TexT* __restrict__ vol,
-                                                  float t_fwd, bool have_fwd, float ex, float ey, float ez, float rx, float ry,
-                                                  float rz, float cx, float cy) {
-    XT t{1.0f, 0};
-    if (have_fwd && t_fwd >= 1e-30f) {
-        t.m = t_fwd;
-        t.renorm();
-        return t;
-    }
-    uint32_t unused = 0;
-    for (int k = 0; k < p.D; ++k) {
-        float ix, iy, s, u, v;
-        plane_coord<AC>(dhw[3 * k] - ez, dhw[3 * k + 1], dhw[3 * k + 2], ex, ey, rx, ry, rz, cx, cy, ix, iy, s, u, v);
-        float smp[4];
-        gather_sample<TexT, false>(vol + static_cast<int64_t>(k) * p.s_plane, p.s_chan, p.s_row, p.Ht, p.Wt, ix, iy, false, unused, smp);
-        t.m *= (1.0f - smp[3]) + 1e-10f;
-        t.renorm();
-    }
-    return t;
-}
 
 // One plane of the back-to-front sweep for one pixel: sample, T_k = T_{k+1}/om_k, gradients d_s[4] of the sample
 // (r, g, b, alpha), suffix sum update.
@@ -336,26 +293,18 @@ constexpr int kB2Flush = 256;                         // + 4 waves that do nothi
 constexpr int kB2Threads = kB2Pix + kB2Flush;
 constexpr int kB2Chunk = 96;
 // The tile of a workgroup and its texel box in LDS (two boxes of Cap 32-bit words).  Round 5: 32 x 16 pixels.  Round 6: 64 x 8 -- a pixel wave is one
-// pixel row, a box line is ~60 texels: fewer, longer lines for the flush (the flush is bound by the part's rate for atomic SEGMENTS of 64 bytes,
-// profiles/r05_backward.txt), and long enough to contain whole aligned 128-byte lines of the gradient volume, which the flush may STORE when no other
-// tile can touch them (OWN below).
+// pixel row, a box line is ~60 texels: fewer, longer lines for the flush, which is bound by the part's rate for atomic SEGMENTS of 64 bytes
+// (profiles/r05_backward.txt): 191 -> 169 segments per 512 pixel-planes, 2.30 -> 2.12 ms at 1024^2 x 32 x 4, 0.352 -> 0.337 at 256^2 x 32 x 8
+// (profiles/r06_backward.txt; the same file has the ownership scheme that was built on top -- plain stores for the aligned 128-byte lines a tile
+// provably owns -- and why it lost).
 template <int TW_, int TH_, int PITCH_, int ROWS_> struct B2Geo {
     static constexpr int TW = TW_, TH = TH_, Pitch = PITCH_, Rows = ROWS_, Cap = Pitch * Rows * 4;
     static_assert(TW * TH == kB2Pix && Pitch <= 96 && Cap % 2 == 0, "one pixel per pixel thread; a box line is at most two 64-column chunks (+ alignment)");
 };
 using B2Tall = B2Geo<32, 16, 56, 27>;   // 23.6 KB per box
 using B2Wide = B2Geo<64, 8, 80, 19>;    // 23.8 KB per box
-constexpr int kBwdDefaultGeo = 3;       // 1 = 32 x 16 tiles (round 5) | 2 = 64 x 8 tiles, atomics only | 3 = 64 x 8 tiles, owned lines stored (profiles/r06_backward.txt)
+constexpr int kBwdDefaultGeo = 2;       // 1 = 32 x 16 tiles (round 5) | 2 = 64 x 8 tiles (profiles/r06_backward.txt)
 
-template <typename TexT> __device__ __forceinline__ void load_pair(const unsigned char* __restrict__ base, uint32_t byte_off, float& a, float& b) {
-    const TexT* __restrict__ q = reinterpret_cast<const TexT*>(base + byte_off);
-    a = to_f32(q[0]), b = to_f32(q[1]);
-}
-template <> __device__ __forceinline__ void load_pair<float>(const unsigned char* __restrict__ base, uint32_t byte_off, float& a, float& b) {
-    float v[2];
-    __builtin_memcpy(v, base + byte_off, 8);  // (one global_load_dwordx2 at dword alignment, uniform base + 32-bit lane offset)
-    a = v[0], b = v[1];
-}
 // round to nearest (floor(x + 0.5)) in one instruction: the staged sums must not be biased -- with a texture much coarser than the image a hundred
 // taps meet in one texel, and a truncating conversion adds up to half a unit of the fixed-point grid PER TAP in one direction
 __device__ __forceinline__ int cvt_rpi(float x) {
@@ -381,7 +330,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
-template <typename TexT, bool AC, typename G, bool OWN>
+template <typename TexT, bool AC, typename G>
 __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(const KParams p, const BwdParams b, const int tiles_x) {
     constexpr int kB2TW = G::TW, kB2TH = G::TH, kB2Pitch = G::Pitch, kB2Rows = G::Rows, kB2Cap = G::Cap;
     __shared__ int4 box[kB2Chunk];        // bx0, by0, nx (<= 0: not staged), ny
@@ -389,9 +338,6 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
     __shared__ float2 pcB[kB2Chunk];      // RN(2/h), headroom bits (as int bits)
     __shared__ uint32_t gmax[kB2Chunk];   // per plane: largest |sample gradient| of the tile, as fp32 bits
     __shared__ uint32_t acc[2][kB2Cap];
-    // OWN: per plane the four lines that bound what OTHER tiles' pixels can reach (see build_tables): (a, b, c') with a x + b y + c' > 0 <=> the whole
-    // bilinear support of texel (x, y) lies on this tile's side
-    __shared__ float4 edges[OWN ? kB2Chunk : 1][4];
     constexpr int kES = static_cast<int>(sizeof(TexT));
     const int tid = threadIdx.x;
     // the role of a WAVE (kB2Pix is a multiple of 64), as a scalar: the two roles run separate loop nests behind a scalar branch -- as
@@ -419,10 +365,8 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
     const float* __restrict__ rdv = p.ray_dir + static_cast<int64_t>(n) * 3 * HW;
 #ifdef GMPI_TUNE
     const bool abl_noglobal = (p.flags & (1u << 20)) != 0, abl_nolds = (p.flags & (1u << 21)) != 0, abl_notaps = (p.flags & (1u << 23)) != 0;
-    // OWN ablations (GMPI_TUNE_SKIP 512 | 1024): the row masks are computed and then dropped (every line atomic) | the flush never looks for groups
-    const bool abl_nostore = (p.flags & (1u << 25)) != 0, abl_nogroups = (p.flags & (1u << 26)) != 0;
 #else
-    constexpr bool abl_noglobal = false, abl_nolds = false, abl_notaps = false, abl_nostore = false, abl_nogroups = false;
+    constexpr bool abl_noglobal = false, abl_nolds = false, abl_notaps = false;
 #endif
     const int Ht = p.Ht, Wt = p.Wt;
     const float cx = AC ? static_cast<float>(Wt - 1) * 0.5f : static_cast<float>(Wt);
@@ -631,81 +575,24 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
             }
             return;
         }
-        if constexpr (!OWN) {
-            for (int c0 = 0; c0 < nx; c0 += 64) {   // (one pass for boxes of up to 64 columns)
-                const bool on = c0 + flane < nx;
-                uint32_t* __restrict__ src0 = bx_acc + c0 + flane;
-                for (int l0 = fw; l0 < nlines; l0 += 4 * kFW) {
-                    int q[4];
+        for (int c0 = 0; c0 < nx; c0 += 64) {   // (one pass for boxes of up to 64 columns)
+            const bool on = c0 + flane < nx;
+            uint32_t* __restrict__ src0 = bx_acc + c0 + flane;
+            for (int l0 = fw; l0 < nlines; l0 += 4 * kFW) {
+                int q[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int line = l0 + u * kFW;
-                        q[u] = (on && line < nlines) ? static_cast<int>(src0[line * kB2Pitch]) : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int line = l0 + u * kFW;
-                        if (q[u] != 0) {
-                            src0[line * kB2Pitch] = 0u;
-                            if (!abl_noglobal)
-                                atomicAdd(gp + (static_cast<uint32_t>(line & 3) * gs_chan + static_cast<uint32_t>(line >> 2) * gs_row + static_cast<uint32_t>(c0)) + flane,
-                                          static_cast<float>(q[u]) * inv);
-                        }
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const int line = l0 + u * kFW;
+                    q[u] = (on && line < nlines) ? static_cast<int>(src0[line * kB2Pitch]) : 0;
                 }
-            }
-        } else {
-            // OWN (round 6): a box line of a 64-pixel-wide tile (~60 texels) contains one (seldom two) ALIGNED 128-byte line of the gradient volume:
-            // columns [s, s + 32) of the box, s = the distance to the next 32-float boundary.  When every one of its 32 cells passes the ownership test
-            // (the bilinear support of the cell lies strictly on this tile's side of the four lines of `edges`: no pixel of another tile -- and, one
-            // view per MPI, of another view -- adds into it) those lanes write their sums with a plain STORE (complete; cells nobody touches get their
-            // zero) instead of an atomic: fewer atomic segments, which is what bounds this kernel.  A 128-byte line receives either stores from one
-            // tile or atomics, never both (a line that gets both ping-pongs between the L2 and the memory side: tools/ubench/global_atomic_rate.hip).
-            // The test is linear in x, so a whole group passes iff its two end columns do: decided ONCE per plane for every box row (lane = row)
-            // into two scalar row masks; the line loop below is the atomics-only loop plus one scalar bit test.
-            const float4 e0 = edges[t][0], e1 = edges[t][1], e2 = edges[t][2], e3 = edges[t][3];
-            const int s0 = (32 - (bx & 31)) & 31;                 // box column of the first 32-float boundary of the gradient volume
-            const bool grouped = s0 + 32 <= nx && nx <= 64 && !abl_nogroups;   // (wave-uniform) the box line holds a whole aligned group and fits one pass
-            // lane -> box column.  Grouped: the aligned group sits in lanes 0..31 -- a store's quarter-waves then each cover one whole 64-byte segment
-            // (the coalescer works per 16 lanes: a group that straddles them is written as partial segments, at the partial-segment rate) -- and the
-            // columns left and right of it in lanes 32..63: [0, s0) first, then [s0 + 32, nx) at their own index.
-            const int col = !grouped ? flane : flane < 32 ? s0 + flane : flane - 32 < s0 ? flane - 32 : flane;
-            uint32_t rows0 = 0u, rows1 = 0u;                      // box rows whose group (lanes 0..31 | lanes 32..63 when s0 == 0 and nx == 64) is this tile's alone
-            if (grouped) {
-                const int y = by + flane;                          // lane = box row
-                const float yf = static_cast<float>(y);
-                auto group_rows = [&](int sg) -> uint32_t {
-                    const float xa = static_cast<float>(bx + sg), xb = static_cast<float>(bx + sg + 31);
-                    auto side = [&](const float4& e) { return fminf(e.x * xa, e.x * xb) + __builtin_fmaf(e.y, yf, e.z) > 0.0f; };
-                    const bool ok = side(e0) && side(e1) && side(e2) && side(e3) && y >= 0 && y < Ht && bx + sg >= 0 && bx + sg + 32 <= Wt && 4 * flane < nlines;
-                    return static_cast<uint32_t>(__ballot(ok));   // (box rows <= 27)
-                };
-                rows0 = group_rows(s0);
-                if (s0 == 0 && nx == 64) rows1 = group_rows(32);
-                if (abl_nostore) rows0 = rows1 = 0u;
-            }
-            const bool lo_half = flane < 32;
-            for (int c0 = 0; c0 < nx; c0 += 64) {                 // (grouped: one pass)
-                const bool on = c0 + col < nx;
-                uint32_t* __restrict__ src0 = bx_acc + c0 + col;
-                float* __restrict__ gpl = gp + c0 + col;
-                for (int l0 = fw; l0 < nlines; l0 += 4 * kFW) {
-                    int q[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int line = l0 + u * kFW;
-                        q[u] = (on && line < nlines) ? static_cast<int>(src0[line * kB2Pitch]) : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int line = l0 + u * kFW;
-                        const bool st0 = ((rows0 >> (line >> 2)) & 1u) != 0u, st1 = ((rows1 >> (line >> 2)) & 1u) != 0u;   // (wave-uniform; rows beyond the box: 0)
-                        float* __restrict__ cell = gpl + (static_cast<uint32_t>(line & 3) * gs_chan + static_cast<uint32_t>(line >> 2) * gs_row);
-                        if (q[u] != 0) src0[line * kB2Pitch] = 0u;
-                        if (!abl_noglobal) {
-                            if (lo_half ? st0 : st1) *cell = static_cast<float>(q[u]) * inv;           // the whole line: zeros included
-                            else if (q[u] != 0) atomicAdd(cell, static_cast<float>(q[u]) * inv);
-                        }
+                for (int u = 0; u < 4; ++u) {
+                    const int line = l0 + u * kFW;
+                    if (q[u] != 0) {
+                        src0[line * kB2Pitch] = 0u;
+                        if (!abl_noglobal)
+                            atomicAdd(gp + (static_cast<uint32_t>(line & 3) * gs_chan + static_cast<uint32_t>(line >> 2) * gs_row + static_cast<uint32_t>(c0)) + flane,
+                                      static_cast<float>(q[u]) * inv);
                     }
                 }
             }
@@ -730,52 +617,15 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
             const float zdiff = dhw[3 * k] - ez, ph = dhw[3 * k + 1], pw = dhw[3 * k + 2];
             float mnx = __builtin_inff(), mxx = -__builtin_inff(), mny = mnx, mxy = mxx;
             float cix[4], ciy[4];   // images of the tile's corner pixels (cx0, cy0), (cx1, cy0), (cx0, cy1), (cx1, cy1)
-            bool finite = true, shrunk = true;   // shrunk: align_corners = False and every corner inside the region mpi.py:98-99 shrinks
+            bool finite = true;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int64_t q = static_cast<int64_t>((c & 2) ? cy1 : cy0) * p.W + ((c & 1) ? cx1 : cx0);
                 float ix, iy, s, u, v;
                 plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[q], rdv[HW + q], rdv[2 * HW + q], cx, cy, ix, iy, s, u, v);
                 finite = finite && (fabsf(ix) < 1e6f) && (fabsf(iy) < 1e6f);
-                shrunk = shrunk && fabsf(u) <= kNarrowScale && fabsf(v) <= kNarrowScale;
                 mnx = fminf(mnx, ix), mxx = fmaxf(mxx, ix), mny = fminf(mny, iy), mxy = fmaxf(mxy, iy);
                 cix[c] = ix, ciy[c] = iy;
-            }
-            if constexpr (OWN) {
-                // Ownership (flush): every pixel that is NOT this tile's lies in one of the four half-planes px <= cx0 - 1, px >= cx1 + 1, py <= cy0 - 1,
-                // py >= cy1 + 1 of the image; a pinhole camera maps each to the half-plane beyond the image of its boundary line (the map pixel -> plane
-                // is a homography, every pixel in front of the camera).  A pixel adds into texel (x, y) iff its sample position lies in the open square
-                // (x - 1, x + 1) x (y - 1, y + 1), so the texel is this tile's alone iff that square lies strictly on this tile's side of all four image
-                // lines: with the unit normal (a, b) pointing to this side, a x + b y + c - |a| - |b| > 0.  Each line goes through the images -- by the
-                // forward's own chain -- of two pixels of the neighbouring row / column; 1/16 texel of margin covers their rounding (~1e-3 texel).  A
-                // side without a neighbour (image border) does not constrain; anything irregular (a degenerate line, this tile's own corner pixel not
-                // ~a pixel inside) gives "never": the plane's cells are all added atomically, as in round 5.
-                const float4 never = make_float4(0.f, 0.f, -1.f, 0.f), unconstrained = make_float4(0.f, 0.f, 1.f, 0.f);
-                auto edge = [&](bool exists, int ax, int ay, int bx_, int by_, float refx, float refy) -> float4 {
-                    if (!exists) return unconstrained;
-                    const int64_t qa = static_cast<int64_t>(ay) * p.W + ax, qb = static_cast<int64_t>(by_) * p.W + bx_;
-                    float pix, piy, qix, qiy, s, ua, va, ub, vb;
-                    plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[qa], rdv[HW + qa], rdv[2 * HW + qa], cx, cy, pix, piy, s, ua, va);
-                    plane_coord<AC>(zdiff, ph, pw, ex, ey, rdv[qb], rdv[HW + qb], rdv[2 * HW + qb], cx, cy, qix, qiy, s, ub, vb);
-                    // align_corners = False: u, v inside [-1, 1] are shrunk by 0.95 (mpi.py:98-99), those outside are not -- the map is a homography only
-                    // INSIDE that region (what lies outside lands beyond every shrunk position, out of this tile's reach): both line points must be inside
-                    if (!AC && !(fabsf(ua) <= kNarrowScale && fabsf(va) <= kNarrowScale && fabsf(ub) <= kNarrowScale && fabsf(vb) <= kNarrowScale)) return never;
-                    const float dx = qix - pix, dy = qiy - piy;
-                    const float len2 = dx * dx + dy * dy;
-                    if (!(len2 > 1e-2f && len2 < 1e12f)) return never;   // (NaN too)
-                    const float rl = 1.0f / sqrtf(len2);
-                    float a = dy * rl, bq = -dx * rl;
-                    float c = -(a * pix + bq * piy);
-                    const float fr = a * refx + bq * refy + c;
-                    if (!(fabsf(fr) > 0.25f && fabsf(fr) < 1e6f)) return never;
-                    if (fr < 0.0f) a = -a, bq = -bq, c = -c;
-                    return make_float4(a, bq, c - fabsf(a) - fabsf(bq) - (1.0f / 16), 0.f);
-                };
-                const bool can = finite && b.own != 0 && (AC || shrunk);
-                edges[t][0] = can ? edge(cx0 > 0, cx0 - 1, cy0, cx0 - 1, cy1, cix[0], ciy[0]) : never;          // left   (this side: the corner pixel (cx0, cy0))
-                edges[t][1] = can ? edge(cx1 < p.W - 1, cx1 + 1, cy0, cx1 + 1, cy1, cix[1], ciy[1]) : never;    // right  ((cx1, cy0))
-                edges[t][2] = can ? edge(cy0 > 0, cx0, cy0 - 1, cx1, cy0 - 1, cix[0], ciy[0]) : never;          // top    ((cx0, cy0))
-                edges[t][3] = can ? edge(cy1 < p.H - 1, cx0, cy1 + 1, cx1, cy1 + 1, cix[2], ciy[2]) : never;    // bottom ((cx0, cy1))
             }
             int4 bb = make_int4(0, 0, 0, 0);
             int hbits = 11;
@@ -894,28 +744,21 @@ static hipError_t launch_backward_t(const KParams& p, const BwdParams& b, bool t
             else hipLaunchKernelGGL((render_backward_tile_kernel<TexT, false>), grid, block, 0, stream, p, b, tiles_x);
             return hipGetLastError();
         }
-        // Round 6: 64 x 8 pixel tiles; with ONE view per MPI and a gradient volume whose rows, channels, planes and MPIs all start on 128-byte
-        // boundaries the flush stores the lines that are provably this tile's alone (OWN, see the kernel).  Several views of one MPI add into the same
-        // cells: atomics only.
+        // Round 6: 64 x 8 pixel tiles (32 x 16 in round 5)
         int geo = kBwdDefaultGeo;
-#ifdef GMPI_TUNE  // GMPI_TUNE_BWD: 1 = round 5's 32 x 16 tiles, 2 = 64 x 8 tiles with atomics only, 3 = 64 x 8 tiles with owned lines stored
+#ifdef GMPI_TUNE  // GMPI_TUNE_BWD: 1 = round 5's 32 x 16 tiles, 2 = 64 x 8 tiles
         static const int env_geo = [] { const char* e = getenv("GMPI_TUNE_BWD"); return e ? atoi(e) : 0; }();
         if (env_geo > 0) geo = env_geo;
 #endif
-        BwdParams bo = b;
-        bo.own = (geo == 3 && (p.flags & (1u << 7)) != 0 /* GMPI_FLAG_GRAD_ZEROED */ && p.view_to_mpi == nullptr && p.views_per_mpi == 1 && p.Wt % 32 == 0 && reinterpret_cast<uintptr_t>(b.g_rgba) % 128 == 0 &&
-                  b.gs_row % 32 == 0 && b.gs_chan % 32 == 0 && b.gs_plane % 32 == 0 && b.gs_mpi % 32 == 0) ? 1 : 0;
-        auto go = [&](auto geo_tag, auto own_tag) {
+        auto go = [&](auto geo_tag) {
             using G = decltype(geo_tag);
-            constexpr bool OWN = decltype(own_tag)::value;
             const int tx = (p.W + G::TW - 1) / G::TW, ty = (p.H + G::TH - 1) / G::TH;
             const dim3 grid2(xcd_grid_per_group(tx * ty, tx * ty), p.N);
-            if (ac) hipLaunchKernelGGL((render_backward_tile2_kernel<TexT, true, G, OWN>), grid2, block2, 0, stream, p, bo, tx);
-            else hipLaunchKernelGGL((render_backward_tile2_kernel<TexT, false, G, OWN>), grid2, block2, 0, stream, p, bo, tx);
+            if (ac) hipLaunchKernelGGL((render_backward_tile2_kernel<TexT, true, G>), grid2, block2, 0, stream, p, b, tx);
+            else hipLaunchKernelGGL((render_backward_tile2_kernel<TexT, false, G>), grid2, block2, 0, stream, p, b, tx);
         };
-        if (geo == 1) go(B2Tall{}, std::false_type{});
-        else if (bo.own) go(B2Wide{}, std::true_type{});
-        else go(B2Wide{}, std::false_type{});
+        if (geo == 1) go(B2Tall{});
+        else go(B2Wide{});
         return hipGetLastError();
     }
     const dim3 block(64, 4), grid((p.W + 63) / 64, (p.H + 3) / 4, p.N);
@@ -926,6 +769,10 @@ static hipError_t launch_backward_t(const KParams& p, const BwdParams& b, bool t
 
 // `tiles`: stage the scatter per pixel tile in LDS (default); false = one pixel per lane, 16 global atomics each
 // (GMPI_VARIANT_GATHER: the simple kernel, kept as the cross-check)
+bool backward_gather_supports(const KParams& p);                                                          // render_backward_gather.hip
+uint64_t backward_gather_workspace_bytes(const KParams& p);                                                // render_backward_gather.hip
+hipError_t launch_backward_gather(const KParams& p, int dtype, const BwdParams& b, bool overwrite, hipStream_t stream);   // render_backward_gather.hip
+
 hipError_t launch_backward(const KParams& p0, int dtype, const float* g_rgb, const float* g_depth, float* g_rgba,
                            const int64_t* gstride, bool tiles, hipStream_t stream) {
     KParams p = p0;
@@ -936,8 +783,18 @@ hipError_t launch_backward(const KParams& p0, int dtype, const float* g_rgb, con
     BwdParams b;
     b.g_rgb = g_rgb, b.g_depth = g_depth, b.g_rgba = g_rgba;
     b.gs_mpi = gstride[0], b.gs_plane = gstride[1], b.gs_chan = gstride[2], b.gs_row = gstride[3];
-    b.own = 0;
     if (p.N > 65535) tiles = false;  // grid.y
+    // Round 6: with a workspace for the sample gradients (gmpi_render_backward_workspace_bytes) the atomics-free pair -- pixel pass + texel gather,
+    // render_backward_gather.hip -- takes the launch: every cell of the gradient is written once by its owner.
+    bool gather = tiles && p.ws != nullptr && backward_gather_supports(p) && p.ws_bytes >= backward_gather_workspace_bytes(p) &&
+                  reinterpret_cast<uintptr_t>(p.ws) % 256 == 0;
+#ifdef GMPI_TUNE  // GMPI_TUNE_BWD = 1 | 2: the tile kernels even with a workspace
+    {
+        static const int env_geo = [] { const char* e = getenv("GMPI_TUNE_BWD"); return e ? atoi(e) : 0; }();
+        if (env_geo == 1 || env_geo == 2) gather = false;
+    }
+#endif
+    if (gather) return launch_backward_gather(p, dtype, b, (p.flags & (1u << 7)) != 0 /* GMPI_FLAG_GRAD_OVERWRITE */, stream);
     switch (dtype) {
         case 0: return launch_backward_t<float>(p, b, tiles, stream);
         case 1: return launch_backward_t<bf16_t>(p, b, tiles, stream);

@@ -61,9 +61,9 @@ class MPIRenderer:
                  use_confined_volume=False, device=torch.device("cpu"),
                  # extensions (keyword-only, defaults = reference behaviour)
                  kernel_variant="auto", strict_order=False, range_check=None, on_out_of_plane="exit",
-                 ray_backend="auto", status_mode="sync"):
+                 ray_backend="auto", status_mode="sync", backward="atomic"):
         self.mpi = MPI(align_corners=mpi_align_corners, variant=kernel_variant, strict_order=strict_order,
-                       range_check=range_check, on_out_of_plane=on_out_of_plane)
+                       range_check=range_check, on_out_of_plane=on_out_of_plane, backward=backward)
         self.use_confined_volume = use_confined_volume
         self.n_mpi_planes = n_mpi_planes
         self.plane_min_d = plane_min_d

@@ -292,6 +292,96 @@ def test_tile_backward_matches_the_all_atomic_kernel(cfg):
     assert np.abs(grads["auto"] - ref_g).max() <= 5e-5 * np.abs(ref_g).max() + 1e-6
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(H=160, W=160, Ht=128, Wt=128, yaw=0.0, pitch=0.0, roll=0.0, vpm=1),
+    dict(H=160, W=192, Ht=192, Wt=160, yaw=0.35, pitch=0.12, roll=0.0, vpm=1),     # tilted: the pixel boxes of the texel tiles shear
+    dict(H=144, W=160, Ht=128, Wt=128, yaw=0.25, pitch=-0.1, roll=0.5, vpm=1),     # in-plane rotation: a texel's candidates are a rotated window
+    dict(H=144, W=160, Ht=128, Wt=128, yaw=0.1, pitch=0.1, roll=1.3, vpm=2),       # nearly a quarter turn; two views of every MPI summed in registers
+    dict(H=96, W=224, Ht=40, Wt=56, yaw=0.3, pitch=0.0, roll=0.2, vpm=1),          # texture coarser than the image: many pixels per texel (wide windows)
+    dict(H=100, W=130, Ht=300, Wt=260, yaw=0.3, pitch=0.1, roll=-0.3, vpm=1),      # texture finer than the image: most texels get nothing
+    dict(H=40, W=1800, Ht=32, Wt=64, yaw=0.2, pitch=0.0, roll=0.0, vpm=1),         # 28 pixels per texel: a pixel box wider than a chunk (column blocks), 58 candidates per row
+])
+def test_gather_backward_matches_autograd_and_is_bit_reproducible(cfg):
+    """MPI(backward="gather") (round 6, render_backward_gather.hip: pixel pass + texel gather, no atomics, no zero-fill): against float64 autograd of
+    the same forward, against the atomic tile kernel, and twice in a row -- every gradient cell is written once, in a fixed order, so the two runs
+    are BIT-identical (the atomic kernels' are not: bench.py's `backward_repeatability`)."""
+    from ml_gmpi_amd import MPI
+    M, D, vpm = 2, 5, cfg["vpm"]
+    N = M * vpm
+    H, W, Ht, Wt = cfg["H"], cfg["W"], cfg["Ht"], cfg["Wt"]
+    rgba = oracle.synth_rgba(63, (M, D, 4, Ht, Wt))
+    ray, eye, zd = _rot_cam(N, H, W, cfg["yaw"], cfg["pitch"], cfg["roll"])
+    dhw = _dhw(M, D, ext=0.30, last=0.6)
+    g = np.random.default_rng(19)
+    gc = g.standard_normal((N, 3, H, W)).astype(np.float32)
+    gd = g.standard_normal((N, 1, H, W)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    grads = {}
+    for mode in ("gather", "gather again", "atomic"):
+        vol = t(rgba).requires_grad_(True)
+        mpi = MPI(align_corners=True, on_out_of_plane="raise", backward=mode.split()[0])
+        out = mpi.render_views(vol, t(dhw), t(ray), t(eye), t(zd), views_per_mpi=vpm, check_last_plane=False)
+        ((out["color"] * t(gc)).sum() + (out["depth"] * t(gd)).sum()).backward()
+        grads[mode] = vol.grad.clone()
+    assert torch.equal(grads["gather"], grads["gather again"])
+    a, b = grads["gather"].cpu().numpy(), grads["atomic"].cpu().numpy()
+    scale = np.abs(b).max()
+    assert scale > 0 and np.isfinite(a).all()
+    assert np.abs(a - b).max() <= 1e-5 * scale, (np.abs(a - b).max(), scale)
+    _, _, ref_g = _ref_grads(rgba, dhw, ray, eye, zd, np.repeat(np.arange(M), vpm), gc, gd, True)
+    assert np.abs(a - ref_g).max() <= 5e-5 * np.abs(ref_g).max() + 1e-6
+
+
+def test_gather_backward_falls_back_and_accumulates():
+    """align_corners=False and a ragged view list take the atomic path whatever `backward` says (same gradients); through the C ABI, a launch
+    WITHOUT GMPI_FLAG_GRAD_OVERWRITE adds into what the buffer holds (read, add, write back -- by the cell's one owner)."""
+    import ctypes
+    from ml_gmpi_amd import MPI, _lib
+    M, D, S = 2, 4, 96
+    rgba = oracle.synth_rgba(64, (M, D, 4, S, S))
+    ray, eye, zd = _rot_cam(3, S, S, 0.2, 0.1, 0.1)
+    dhw = _dhw(M, D, ext=0.30, last=0.6)
+    g = np.random.default_rng(20)
+    gc = g.standard_normal((3, 3, S, S)).astype(np.float32)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    v2m = np.array([0, 1, 1], dtype=np.int32)
+    res = {}
+    for mode in ("gather", "atomic"):
+        for ac in (True, False):
+            vol = t(rgba).requires_grad_(True)
+            out = MPI(align_corners=ac, on_out_of_plane="raise", backward=mode).render_views(vol, t(dhw), t(ray), t(eye), t(zd), view_to_mpi=t(v2m), check_last_plane=False)
+            (out["color"] * t(gc)).sum().backward()
+            res[(mode, ac)] = vol.grad.cpu().numpy()
+    for ac in (True, False):
+        sc = np.abs(res[("atomic", ac)]).max()
+        assert np.abs(res[("gather", ac)] - res[("atomic", ac)]).max() <= 1e-5 * sc
+    # accumulate semantics of the gather path (no OVERWRITE flag): grad = 1 + gradient
+    lib = _lib.load_library()
+    vol = t(rgba[:2])
+    ray2, eye2, zd2 = t(ray[:2]), t(eye[:2]), t(zd[:2])
+    mpi = MPI(align_corners=True, on_out_of_plane="raise")
+    fwd = mpi.render_views(vol, t(dhw), ray2, eye2, zd2, views_per_mpi=1, check_last_plane=False, want_transmittance=True, defer_status=True, _in_autograd_fn=True)
+    p, keep = fwd["_bwd"]
+    p.rgb_out = p.depth_out = p.status = None
+    need = int(lib.gmpi_render_backward_workspace_bytes(ctypes.byref(p)))
+    assert need >= 2 * D * S * S * 24
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    p.workspace, p.workspace_bytes = ws.data_ptr(), need
+    gcol = t(gc[:2])
+    outs = []
+    for flag, fill in ((_lib.FLAG_GRAD_OVERWRITE, float("nan")), (0, 1.0)):
+        p.flags = (p.flags & ~_lib.FLAG_GRAD_OVERWRITE) | flag
+        grad = torch.full_like(vol, fill)
+        gs = (ctypes.c_int64 * 5)(*grad.stride())
+        _lib.check(lib.gmpi_mpi_render_backward_launch(ctypes.byref(p), gcol.data_ptr(), None, grad.data_ptr(), gs, torch.cuda.current_stream(dev).cuda_stream), "bwd")
+        torch.cuda.synchronize()
+        outs.append(grad)
+    assert torch.isfinite(outs[0]).all()                      # OVERWRITE: every element written, whatever the buffer held
+    assert torch.equal(outs[1], outs[0] + 1.0)                # without it: added to the ones, cell by cell
+
+
 def test_tile_backward_several_views_per_mpi_keep_their_atomics():
     """Two views of ONE MPI add into the same gradient volume."""
     from ml_gmpi_amd import MPI

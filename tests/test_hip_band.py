@@ -116,11 +116,12 @@ def test_band_range_check_has_no_false_alarm_on_nan_and_huge_rays(dtype):
         out = hip_render(vol, dhw, bad, eye, zd, variant="band", strict=strict, check_last=False)
         assert int(out["status"][0]) == 0, (strict, out["status"][:4])
         if strict:
-            ok = np.ones(clean["color"].shape[-2:], dtype=bool)
-            for n, ys, xs in ((0, slice(40, 43), slice(100, 170)), (1, slice(200, 201), slice(7, 8)), (1, slice(13, 14), slice(250, 251))):
-                m = ok.copy(); m[ys, xs] = False
+            good = np.ones((2,) + clean["color"].shape[-2:], dtype=bool)     # every pixel but the ones with a bad ray
+            good[0, 40:43, 100:170] = False
+            good[1, 200, 7] = good[1, 13, 250] = False
+            for n in range(2):
                 for k in ("color", "depth", "T"):
-                    assert np.array_equal(out[k][n][:, m], clean[k][n][:, m]), (n, k)
+                    assert np.array_equal(out[k][n][:, good[n]], clean[k][n][:, good[n]]), (n, k)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])

@@ -9,10 +9,10 @@ cd "$(dirname "$0")/../ml-gmpi_amd/csrc"
 B=../../build/tune$SUFFIX; mkdir -p $B
 TUNE=-DGMPI_TUNE; [ -n "$NOTUNE" ] && TUNE=
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function $TUNE $*"
-ALL="gmpi_abi render_gather render_lds render_band render_wave render_backward light_kernels"
+ALL="gmpi_abi render_gather render_lds render_band render_wave render_backward render_backward_gather light_kernels"
 for s in $ALL; do
   if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $s "; then cp ../../build/tune/$s.o $B/$s.o; continue; fi
-  if [ ! -f $B/$s.o ] || [ $s.hip -nt $B/$s.o ] || [ gmpi_device.hpp -nt $B/$s.o ] || [ -n "$FORCE" ] || [ -n "$ONLY" ]; then
+  if [ ! -f $B/$s.o ] || [ $s.hip -nt $B/$s.o ] || [ gmpi_device.hpp -nt $B/$s.o ] || [ gmpi_backward.hpp -nt $B/$s.o ] || [ ../../include/gmpi_render.h -nt $B/$s.o ] || [ -n "$FORCE" ] || [ -n "$ONLY" ]; then
     rm -f $B/$s.o; /opt/rocm/bin/hipcc $FLAGS -c $s.hip -o $B/$s.o &
   fi
 done

@@ -2,7 +2,7 @@
 kernel) against the one-pixel-per-lane kernel (GMPI_VARIANT_GATHER: 16 global atomics per pixel and plane, no staging) on random image / texture
 sizes, plane counts (incl. more than one table chunk of 96), storage types, align_corners, views per MPI (uniform, ragged through view_to_mpi),
 tilted and rotated pinhole cameras, exactly / nearly opaque planes, with and without a depth gradient and a forward transmittance.
-usage: python tools/fuzz_backward_gpu.py [n_cases] [seed]"""
+usage: python tools/fuzz_backward_gpu.py [n_cases] [seed]    (FUZZ_BWD=gather: the atomics-free pair of round 6 in place of the tile kernel)"""
 import os
 import sys
 import time
@@ -72,7 +72,7 @@ for i in range(n_cases):
     grads = {}
     for variant in ("auto", "gather"):
         vol = t(rgba).to(dtype).requires_grad_(True)
-        mpi = MPI(align_corners=ac, variant=variant, on_out_of_plane="raise", range_check="off")
+        mpi = MPI(align_corners=ac, variant=variant, on_out_of_plane="raise", range_check="off", backward=os.environ.get("FUZZ_BWD", "atomic") if variant == "auto" else "atomic")
         kw = dict(view_to_mpi=t(v2m)) if v2m is not None else dict(views_per_mpi=vpm)
         out = mpi.render_views(vol, t(dhw), t(ray), t(eye), t(zd), check_last_plane=False, **kw)
         loss = (out["color"] * t(gc)).sum()

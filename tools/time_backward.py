@@ -35,7 +35,12 @@ for S, B in ((256, 8), (512, 4), (1024, 4)):
                              defer_status=True, _in_autograd_fn=True)
     p, keep = res["_bwd"]
     p.rgb_out = p.depth_out = None
-    p.flags |= _lib.FLAG_GRAD_ZEROED   # (what the autograd bridge passes: it has just zero-filled the gradient volume)
+    need = int(lib.gmpi_render_backward_workspace_bytes(ctypes.byref(p))) if os.environ.get("BWD_GATHER") else 0   # BWD_GATHER=1: the atomics-free pair
+    bws = torch.empty(need, dtype=torch.uint8, device=dev) if need else None   # (what the autograd bridge passes: the atomics-free path writes every element)
+    if bws is not None:
+        p.workspace, p.workspace_bytes = bws.data_ptr(), bws.numel()
+        p.flags |= _lib.FLAG_GRAD_OVERWRITE
+    print("   backward workspace:", need, "bytes", flush=True)
     prof = torch.zeros(64, dtype=torch.int32, device=dev)
     p.status = prof.data_ptr() if os.environ.get("GMPI_PROF_WORDS") else None
     grad = torch.zeros_like(vol)
