@@ -354,11 +354,30 @@ class TrainWorkload:
             return sum(e0.elapsed_time(e1) for e0, e1 in evs) / n
         with torch.no_grad():
             fwd_ms, zero_ms, bwd_ms = timed(k["fwd"]), timed(k["grad"].zero_), timed(k["bwd"])
+            # the opt-in atomics-free pair (MPI(backward="gather"): pixel pass + texel gather, no zero-fill, bit-reproducible), for the record
+            gather_ms = None
+            if k["needs_zero_fill"]:
+                import ctypes
+                from ml_gmpi_amd import _lib
+                lib = _lib.load_library()
+                ps = k["pstruct"]
+                need = int(lib.gmpi_render_backward_workspace_bytes(ctypes.byref(ps)))
+                if need:
+                    try:
+                        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                        keep = (ps.workspace, ps.workspace_bytes, ps.flags)
+                        ps.workspace, ps.workspace_bytes, ps.flags = ws.data_ptr(), need, ps.flags | _lib.FLAG_GRAD_OVERWRITE
+                        gather_ms = timed(k["bwd"])
+                        ps.workspace, ps.workspace_bytes, ps.flags = keep
+                        del ws
+                    except torch.cuda.OutOfMemoryError:
+                        pass
         self.r.mpi.raise_on_status(k["status"])
         return dict(forward_ms=round(fwd_ms, 4), forward_frac=round(self.ab_fwd / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     grad_zero_fill_ms=round(zero_ms, 4), backward_ms=round(bwd_ms, 4),
                     backward_frac=round(self.ab_bwd / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), backward_algorithmic_bytes=self.ab_bwd,
-                    what=f"each part alone: {n} launches, HIP events on the launch stream")
+                    backward_gather_ms=None if gather_ms is None else round(gather_ms, 4),
+                    what=f"each part alone: {n} launches, HIP events on the launch stream; backward_gather_ms: the opt-in atomics-free pair (no zero-fill)")
 
     def parity(self, n_windows=2, w=64):
         """The backward against (1) the all-atomic one-pixel-per-lane kernel (GMPI_VARIANT_GATHER: no staging, no tiles, 16 global fp32 atomics per
@@ -776,7 +795,7 @@ def companion_lines(a, dev, main_name):
         parts = tw.parts()
         step_ms = parts["forward_ms"] + parts["grad_zero_fill_ms"] + parts["backward_ms"]
         ent = dict(workload=tw.desc + " (curriculums.py:89-91, train.py:740-779)", forward_ms=parts["forward_ms"], grad_zero_fill_ms=parts["grad_zero_fill_ms"],
-                   backward_ms=parts["backward_ms"], ms=round(step_ms, 4), forward_frac=parts["forward_frac"], backward_frac=parts["backward_frac"],
+                   backward_ms=parts["backward_ms"], backward_gather_ms=parts["backward_gather_ms"], ms=round(step_ms, 4), forward_frac=parts["forward_frac"], backward_frac=parts["backward_frac"],
                    algorithmic_bytes_per_launch=tw.ab_fwd + tw.ab_bwd, frac=round((tw.ab_fwd + tw.ab_bwd) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    what="forward | zero-fill | backward each alone: 20 launches behind 3 warm-ups, HIP events on the launch stream; ms = their sum")
         if not a.no_parity:
