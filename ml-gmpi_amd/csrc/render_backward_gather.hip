@@ -23,6 +23,7 @@
 // MPI (several views of one MPI are summed in registers), a workspace of N D H W 16 bytes lent by the caller (gmpi_render_backward_workspace_bytes).
 #include "gmpi_backward.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace gmpi {
@@ -480,9 +481,13 @@ static hipError_t launch_gather_t(const KParams& p, const BwdParams& b, bool ove
     }
     {
         const int tx = (p.Wt + kTX - 1) / kTX, ty = (p.Ht + kTY - 1) / kTY;
-        // planes per workgroup: as many as keep >= ~4 workgroups per CU in the launch (a workgroup pipelines its planes: the more the better)
-        int ppw = p.D;
+        // planes per workgroup: 4-8 measured best at the G-step shapes (1 ... 32: within 5 %, profiles/r06_backward.txt); fewer when the launch is small
+        int ppw = std::min(p.D, 8);
         while (ppw > 1 && static_cast<int64_t>(tx) * ty * p.M * ((p.D + ppw - 1) / ppw) < 1024) ppw = (ppw + 1) / 2;
+#ifdef GMPI_TUNE  // GMPI_TUNE_PPW: planes per workgroup of the texel pass
+        static const int env_ppw = [] { const char* e = getenv("GMPI_TUNE_PPW"); return e ? atoi(e) : 0; }();
+        if (env_ppw > 0) ppw = std::min(env_ppw, p.D);
+#endif
         const dim3 grid(xcd_grid_per_group(tx * ty, tx * ty), (p.D + ppw - 1) / ppw, p.M);
         if (overwrite) hipLaunchKernelGGL((texel_gather_kernel<true>), grid, dim3(kTT), 0, stream, p, b, P, G, recs, tx, ty, ppw);
         else hipLaunchKernelGGL((texel_gather_kernel<false>), grid, dim3(kTT), 0, stream, p, b, P, G, recs, tx, ty, ppw);
