@@ -204,8 +204,9 @@ def run_video(a, dev, rank, world, use_dist):
     drv = ml_gmpi_amd.ViewBatchDriver(r, batch=8)
 
     def batched_pass():
-        res = drv.render_path(rgba, S, angles, [0.0] * len(angles), to_uint8=True, depth_range=(near, far))
-        return drv.to_host(res["img8"], res["dep8"])  # (pinned buffers of the driver: a pageable `.cpu()` per pass costs its page faults on top)
+        # (round 6: the uint8 frames of a batch travel to pinned host buffers on a second stream while the next batch renders)
+        res = drv.render_path(rgba, S, angles, [0.0] * len(angles), to_uint8=True, depth_range=(near, far), to_host=True)
+        return res["img8_host"], res["dep8_host"]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -252,7 +253,7 @@ def run_video(a, dev, rank, world, use_dist):
                                 "what": "render(): host time of the call | .cpu() x 2: waits for the kernel, copies 4 MB | the script's own uint8 conversion (numpy)"},
                 "render_and_copy_views_per_s": round(len(angles) * a.steps * world / (in_render + to_host), 1),
                 "batched_driver": {"views_per_s": round(views / t_batch, 1), "ms_per_view": round(t_batch / views * world * 1e3, 4), "batch": 8,
-                                   "what": "ViewBatchDriver.render_path: 8 views per launch, uint8 epilogue on the device, one copy per pass into pinned host buffers"},
+                                   "what": "ViewBatchDriver.render_path(to_host=True): 8 views per launch, uint8 epilogue on the device per batch, copies into pinned host buffers on a second stream next to the next batch's render"},
                 "frames_identical": bool(same), "roofline": None, "cpu_baseline": None}
         print(json.dumps(line), flush=True)
     if use_dist:

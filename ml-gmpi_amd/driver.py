@@ -33,18 +33,21 @@ def shard_views(n_views: int, rank: int, world_size: int, mode: str = "strided")
     raise ValueError(mode)
 
 
-def frames_to_uint8(rgb_pm1: torch.Tensor, depth: Optional[torch.Tensor], near: float, far: float):
-    """(img8 [N,H,W,3] uint8, dep8 [N,H,W,1] uint8 or None) on the device -- render_video.py:118-126."""
+def frames_to_uint8(rgb_pm1: torch.Tensor, depth: Optional[torch.Tensor], near: float, far: float, out=None):
+    """(img8 [N,H,W,3] uint8, dep8 [N,H,W,1] uint8 or None) on the device -- render_video.py:118-126.  `out` = (img8, dep8 or None): contiguous
+    device tensors to write into (e.g. slices of a path-long buffer)."""
     if not rgb_pm1.is_cuda:
         raise _lib.GmpiError("frames_to_uint8 needs device tensors (no CPU path)")
     lib = _lib.load_library()
     rgb_pm1 = rgb_pm1.contiguous()
     N, _, H, W = rgb_pm1.shape
-    img8 = torch.empty((N, H, W, 3), dtype=torch.uint8, device=rgb_pm1.device)
+    img8 = out[0] if out is not None else torch.empty((N, H, W, 3), dtype=torch.uint8, device=rgb_pm1.device)
+    assert img8.is_contiguous() and tuple(img8.shape) == (N, H, W, 3) and img8.dtype is torch.uint8
     dep8 = None
     if depth is not None:
         depth = depth.contiguous()
-        dep8 = torch.empty((N, H, W, 1), dtype=torch.uint8, device=rgb_pm1.device)
+        dep8 = out[1] if out is not None else torch.empty((N, H, W, 1), dtype=torch.uint8, device=rgb_pm1.device)
+        assert dep8.is_contiguous() and tuple(dep8.shape) == (N, H, W, 1) and dep8.dtype is torch.uint8
     with torch.cuda.device(rgb_pm1.device):
         _lib.check(lib.gmpi_frames_to_uint8_launch(
             rgb_pm1.data_ptr(), depth.data_ptr() if depth is not None else None, N, H, W, float(near), float(far),
@@ -138,6 +141,16 @@ class ViewBatchDriver:
         self.renderer = renderer
         self.batch = int(batch)
         self._host = {}
+        self._copy_stream = None   # a second HIP stream: frames travel to the host while the next batch renders (render_path(to_host=True))
+
+    def _pinned(self, slot, shape, dtype):
+        key = (slot, tuple(shape), dtype)
+        buf = self._host.get(key)
+        if buf is None:
+            while len(self._host) >= 8:
+                self._host.pop(next(iter(self._host)))
+            buf = self._host[key] = torch.empty(shape, dtype=dtype, pin_memory=True)
+        return buf
 
     def to_host(self, *tensors: torch.Tensor):
         """Device tensors -> PINNED host tensors kept by the driver, one asynchronous copy each and one synchronisation.  A fresh pageable
@@ -145,12 +158,7 @@ class ViewBatchDriver:
         run to run; 9 k steadily this way).  The buffers are reused by the next call with the same shapes: consume (or copy) them first."""
         outs = []
         for i, t in enumerate(tensors):
-            key = (i, tuple(t.shape), t.dtype)
-            buf = self._host.get(key)
-            if buf is None:
-                while len(self._host) >= 8:
-                    self._host.pop(next(iter(self._host)))
-                buf = self._host[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=t.is_cuda)
+            buf = self._pinned(i, t.shape, t.dtype) if t.is_cuda else torch.empty(t.shape, dtype=t.dtype)
             buf.copy_(t, non_blocking=True)
             outs.append(buf)
         if tensors and tensors[0].is_cuda:
@@ -160,11 +168,14 @@ class ViewBatchDriver:
     @torch.no_grad()
     def render_path(self, mpi_rgbas: torch.Tensor, render_size: int, yaws: Sequence[float],
                     pitches: Sequence[float], indices: Optional[Sequence[int]] = None, to_uint8: bool = False,
-                    depth_range=None, want_transmittance: bool = False):
+                    depth_range=None, want_transmittance: bool = False, to_host: bool = False):
         """Views `indices` (default all) of ONE MPI [1,D,4,Ht,Wt] along (yaws[i], pitches[i]) -- the loop of
         render_video.py:95-130 (h_mean/v_mean = angle, std 0) as batched launches.
 
         Returns dict(rgb [n,3,H,W] in [-1,1], depth [n,1,H,W][, T][, img8, dep8]) on the device.
+        `to_host=True` (with `to_uint8`; round 6): the uint8 epilogue runs per batch and every batch's frames travel to PINNED host buffers on a second
+        HIP stream while the next batch renders -- the copy of the whole path (64 frames of 512^2: 67 MB) then hides behind the render launches instead
+        of following them; adds `img8_host`, `dep8_host` (buffers of the driver, reused by the next call of the same shape: consume or copy them).
         """
         r = self.renderer
         assert mpi_rgbas.shape[0] == 1, "render_path draws many views of one MPI"
@@ -178,26 +189,57 @@ class ViewBatchDriver:
         if render_size != r.render_h or render_size != r.render_w:
             r.set_cam(r.cam_fov, render_size, render_size)
         dhw = r._dhw_on_device()
+        pipe = to_host and to_uint8 and mpi_rgbas.is_cuda
+        if pipe:
+            near, far = depth_range if depth_range is not None else (r.plane_min_d, r.plane_max_d)
+            img8 = torch.empty((n, render_size, render_size, 3), dtype=torch.uint8, device=dev)
+            dep8 = torch.empty((n, render_size, render_size, 1), dtype=torch.uint8, device=dev)
+            img8_h, dep8_h = self._pinned("path_img8", img8.shape, torch.uint8), self._pinned("path_dep8", dep8.shape, torch.uint8)
+            if self._copy_stream is None or self._copy_stream.device != dev:
+                self._copy_stream = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            self._copy_stream.wait_stream(main)   # (the buffers' previous users are done)
+        # Poses and rays of a GROUP of batches in one go (round 6): one pass of the host's pose arithmetic, one copy, one ray kernel for up to
+        # ~256 MB of rays -- per batch only the render launch is left on the host (the per-batch pose call was what bounded the loop once the
+        # copies had moved off the critical path).  The poses are a pure function of the angles (std 0); the torch RNG advances as for ONE
+        # `sample_cam_poses` call per group (the reference's per-view loop advances it once per view: render_video.py:100-113).
+        group = max(self.batch, (int(256e6 // (12 * render_size * render_size)) // self.batch) * self.batch)
+        ray_g = eye_g = zd_g = None
         for s in range(0, n, self.batch):
             chunk = idx[s:s + self.batch]
-            gy = torch.tensor([[float(yaws[i])] for i in chunk], dtype=torch.float32)
-            gp = torch.tensor([[float(pitches[i])] for i in chunk], dtype=torch.float32)
-            _, _, c2w, rays, eyes, zdirs = r.sample_cam_poses(len(chunk), 0.0, 0.0, 0.0, 0.0, False,
-                                                              given_yaws=gy, given_pitches=gp)
+            if s % group == 0:
+                members = idx[s:s + group]
+                gy = torch.tensor([[float(yaws[i])] for i in members], dtype=torch.float32)
+                gp = torch.tensor([[float(pitches[i])] for i in members], dtype=torch.float32)
+                _, _, c2w, rays, eyes, zdirs = r.sample_cam_poses(len(members), 0.0, 0.0, 0.0, 0.0, False, given_yaws=gy, given_pitches=gp)
+                if r._batched_cam is not None and rays is r._batched_cam[0]:
+                    ray_g, eye_g, zd_g = r._batched_cam[1:]
+                else:
+                    ray_g, eye_g, zd_g = torch.cat(rays), torch.cat(eyes), torch.cat(zdirs)
+                r._batched_cam = None
+            g0 = s % group
+            ray_t, eye_t, zd_t = ray_g[g0:g0 + len(chunk)], eye_g[g0:g0 + len(chunk)], zd_g[g0:g0 + len(chunk)]
             out = dict(color=rgb[s:s + len(chunk)], depth=dep[s:s + len(chunk)])
             if T is not None:
                 out["T"] = T[s:s + len(chunk)]
-            if r._batched_cam is not None and rays is r._batched_cam[0]:
-                ray_t, eye_t, zd_t = r._batched_cam[1:]
-            else:
-                ray_t, eye_t, zd_t = torch.cat(rays), torch.cat(eyes), torch.cat(zdirs)
-            r._batched_cam = None
             r.mpi.render_views(mpi_rgbas, dhw, ray_t, eye_t, zd_t,
                                views_per_mpi=len(chunk), check_last_plane=True, out_pm1=True,
                                want_transmittance=want_transmittance, status=status, defer_status=True, out=out)
+            if pipe:   # this batch's frames: uint8 on the device, then to the host behind an event -- next to the next batch's render
+                e = s + len(chunk)
+                frames_to_uint8(rgb[s:e], dep[s:e], near, far, out=(img8[s:e], dep8[s:e]))
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self._copy_stream):
+                    self._copy_stream.wait_event(ev)
+                    img8_h[s:e].copy_(img8[s:e], non_blocking=True)
+                    dep8_h[s:e].copy_(dep8[s:e], non_blocking=True)
         r.mpi.raise_on_status(status)  # one host sync for the whole path
         res = dict(rgb=rgb, depth=dep, T=T)
-        if to_uint8:
+        if pipe:
+            self._copy_stream.synchronize()
+            res.update(img8=img8, dep8=dep8, img8_host=img8_h, dep8_host=dep8_h)
+        elif to_uint8:
             near, far = depth_range if depth_range is not None else (r.plane_min_d, r.plane_max_d)
             res["img8"], res["dep8"] = frames_to_uint8(rgb, dep, near, far)
         return res

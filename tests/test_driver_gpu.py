@@ -37,6 +37,12 @@ def test_render_path_equals_per_view_renders_and_oracle():
     assert h_img.is_pinned() and not h_img.is_cuda and torch.equal(h_img, out["img8"].cpu()) and torch.equal(h_dep, out["dep8"].cpu())
     again = drv.to_host(out["img8"], out["dep8"])
     assert again[0].data_ptr() == h_img.data_ptr() and again[1].data_ptr() == h_dep.data_ptr()
+    # round 6: the same frames through the pipelined path (uint8 epilogue per batch, copies on a second stream next to the next batch's render)
+    piped = drv.render_path(rgba, S, yaws, pitches, to_uint8=True, to_host=True)
+    assert piped["img8_host"].is_pinned() and torch.equal(piped["img8_host"], out["img8"].cpu()) and torch.equal(piped["dep8_host"], out["dep8"].cpu())
+    assert torch.equal(piped["img8"], out["img8"]) and torch.equal(piped["rgb"], out["rgb"])
+    sub = drv.render_path(rgba, S, yaws, pitches, indices=[5, 1, 2, 6], to_uint8=True, to_host=True)   # a rank's shard of the path
+    assert torch.equal(sub["img8_host"], out["img8"].cpu()[[5, 1, 2, 6]])
 
 
 def test_render_seeds_and_views_per_mpi_match_expanded_volume():
