@@ -34,9 +34,9 @@ pmc cfg3 tcc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum
 # the G-step shapes (forward + backward): trace + FETCH / WRITE / issue counters of both kernels
 for wl in ${TRAIN:-train256 train1024}; do
   mkdir -p $OUT/$wl
-  timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$wl/trace -o t -- python bench.py --workload $wl --steps 20 --warmup 5 > $OUT/$wl/bench_trace.log 2>&1
+  timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$wl/trace -o t -- python bench.py --workload $wl --steps 20 --warmup 5 --no-parity > $OUT/$wl/bench_trace.log 2>&1
   pmc_t() { local name=$1; shift
-    timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$wl/pmc_$name -o p -- python bench.py --workload $wl --steps 8 --warmup 2 --prewarm-ms 0 > $OUT/$wl/bench_$name.log 2>&1
+    timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$wl/pmc_$name -o p -- python bench.py --workload $wl --steps 8 --warmup 2 --prewarm-ms 0 --no-parity > $OUT/$wl/bench_$name.log 2>&1
     echo "$wl $name rc=$?"; }
   pmc_t fetch FETCH_SIZE
   pmc_t write WRITE_SIZE
