@@ -42,15 +42,20 @@ struct KParams {
     uint32_t* gate;
     uint32_t gate_gen, gate_sense;
     int32_t band_cols;  // band kernel: band columns per XCD window (render_band.hip band_pos; set by launch_band)
+    int32_t band_rot;   // band kernel: per-view rotation of the XCD <-> run assignment (xcd_item_per_group)
 };
 
 // blockIdx -> work item (pixel tile / band), "per view group" form: XCD x = blockIdx % 8 (workgroups are dealt round-robin to the 8 XCDs)
 // gets a contiguous run of the items of EVERY group of views that share an MPI, so that row-major neighbours meet in one L2 AND the XCDs walk
 // the views together -- a launch that only renders some of the views (gate) still fills every XCD.  Returns n_items for "no item".
-__device__ __forceinline__ int xcd_item_per_group(int block, int group_items, int n_items) {
+// `rot`: group g hands XCD x the run that XCD (x + g rot) % 8 would get in group 0.  The dispatcher deals workgroups to the XCDs round-robin and NO work moves
+// between XCDs afterwards: a launch ends when the most loaded XCD is done.  With rot = 0 every XCD renders the same region of every view; regions differ in
+// cost (the camera's keystone makes the texel boxes of some band rows taller: a third DMA pass), and what is expensive in one view tends to be expensive in the
+// next: rotating the assignment per view averages that out (round 6, render_band.hip; measured per XCD with s_memtime stamps: profiles/r06_band_order.txt).
+__device__ __forceinline__ int xcd_item_per_group(int block, int group_items, int n_items, int rot = 0) {
     const int per_xcd = (group_items + 7) / 8, n_groups = (n_items + group_items - 1) / group_items;
     const int jb = block / 8, grp = jb / per_xcd, rr = jb - grp * per_xcd;
-    const int in_group = (block % 8) * per_xcd + rr;
+    const int in_group = ((block + grp * rot) % 8) * per_xcd + rr;
     const int item = grp * group_items + in_group;
     return (grp >= n_groups || in_group >= group_items || item >= n_items) ? n_items : item;
 }

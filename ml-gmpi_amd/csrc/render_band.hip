@@ -44,6 +44,12 @@ constexpr float kBoxEps = 1.0f / 64;
 // is 1.5-4.6 % faster there although it moves more bytes (1.142 x against 1.079 x) -- not a channel or XCD imbalance (TCC_EA0_RDREQ / TCC_BUSY per
 // channel are flat to 0.1 % in every order), not the position in the run sequence, and box-dependent (one box of three shows no difference).
 constexpr int kWindowCols16 = 2, kWindowCols32 = 2, kWindowCols32Deep = 1, kDeepPlanes = 128;
+// Per-view rotation of the XCD <-> run assignment (gmpi_device.hpp xcd_item_per_group; round 6).  Workgroups are dealt to the XCDs round-robin and stay there: a launch
+// ends when the most loaded XCD is done, and with every XCD rendering the SAME region of every view the regional cost differences (keystone: taller boxes, a third DMA
+// pass) add up over the views -- s_memtime stamps per workgroup (tools/kbench KB_STAMPS=1): the busiest XCD carries 3.6 % more than the mean on config 3.  Rotating the
+// assignment by one XCD per view: config 3 bf16 0.7982 -> 0.7743 ms (-3.0 %) and 0.7856 -> 0.7676 (-2.3 %) on two boxes, four / three alternating repeats; fp32 -1.2 % / -0.8 %;
+// config 5 -0.3 % / -1 %; a rotation by 3 is as good on 16-bit volumes and worse on config 5 (profiles/r06_band_order.txt).
+constexpr int kViewRotation = 1;
 constexpr float kCoordLimit = 16384.0f;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     // ---- blockIdx -> band.  XCD x = blockIdx % 8 gets a contiguous run of the bands of EVERY view (group of views that share an MPI): neighbours
     //      (column-major since round 5, see below) share halo rows in one L2, and the XCDs walk the views together (measured 4 % faster than one run of all bands per XCD,
     //      where different XCDs read different views at the same time) ----
-    int band_id = xcd_item_per_group(blockIdx.x, bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands);
+    int band_id = xcd_item_per_group(blockIdx.x, bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands, p.band_rot);
 #ifdef GMPI_TUNE  // (experiment: one contiguous run of ALL bands per XCD)
     if (p.flags & (1u << 19)) band_id = static_cast<int>(blockIdx.x % 8) * ((n_bands + 7) / 8) + static_cast<int>(blockIdx.x / 8);
 #endif
@@ -336,6 +342,11 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     if (view_gated_out(p, n)) return;  // (AUTO: a view with a box that does not fit is the tile kernel's)
     int bxi, byi;
     band_pos(brem, bands_x, bands_y, p.band_cols, bxi, byi);
+#ifdef GMPI_TUNE  // GMPI_TUNE_WAVE + 16384: every workgroup leaves (start, end, XCC id) in status[64 + 3 blockIdx ...] (tools/kbench KB_STAMPS=1: who finishes when, per XCD)
+    const bool stamp = (p.flags & (1u << 22)) != 0 && p.status != nullptr;
+    uint64_t stamp_start = 0;
+    if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_start));
+#endif
 
     const int tid = threadIdx.x;
     // Registers are the scarce resource (64 per lane for 8 waves per SIMD): values that only depend on the thread index are
@@ -867,6 +878,14 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
         }
     }
     report_status(p.status, bad);
+#ifdef GMPI_TUNE
+    if (stamp && threadIdx.x == 0) {
+        uint64_t stamp_end;
+        uint32_t xcc;
+        asm volatile("s_memtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_end), "=s"(xcc));
+        p.status[64 + 3 * blockIdx.x] = static_cast<uint32_t>(stamp_start), p.status[65 + 3 * blockIdx.x] = static_cast<uint32_t>(stamp_end), p.status[66 + 3 * blockIdx.x] = xcc & 15u;
+    }
+#endif
 #ifdef GMPI_PROF
     if (p.status != nullptr && band_id == 700 && threadIdx.x == 320) {  // one wave in the middle of the launch
         uint64_t now_;
@@ -951,10 +970,13 @@ bool band_variant_supports(const KParams& p, int dtype) {
 hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
     p.band_cols = dtype != 0 ? band::kWindowCols16 : p.D > band::kDeepPlanes ? band::kWindowCols32Deep : band::kWindowCols32;
+    p.band_rot = band::kViewRotation;
 #ifdef GMPI_TUNE  // profiling builds: tune bits 8-9 = ablations (no memory traffic / no compositing); GMPI_TUNE_ORDER = band columns per XCD window
     p.flags |= static_cast<uint32_t>((tune >> 8) & 127) << 16;
     static const int env_order = [] { const char* e = getenv("GMPI_TUNE_ORDER"); return e ? atoi(e) : 0; }();
     if (env_order > 0) p.band_cols = env_order;
+    static const int env_rot = [] { const char* e = getenv("GMPI_TUNE_ROT"); return e ? atoi(e) : -1; }();
+    if (env_rot >= 0) p.band_rot = env_rot;
 #else
     (void)tune;
 #endif

@@ -65,7 +65,8 @@ int main(int argc, char** argv) {
     const size_t es = dt == 0 ? 4 : 2, nvol = (size_t)N * D * 4 * S * S, npix = (size_t)N * S * S;
     void* vol; float *d_dhw, *d_eye, *d_zd, *d_ray, *d_rgb, *d_dep; uint32_t* d_st;
     CK(hipMalloc(&vol, nvol * es)); CK(hipMalloc(&d_dhw, dhw.size() * 4)); CK(hipMalloc(&d_eye, eye.size() * 4)); CK(hipMalloc(&d_zd, zd.size() * 4));
-    CK(hipMalloc(&d_ray, ray.size() * 4)); CK(hipMalloc(&d_rgb, npix * 3 * 4)); CK(hipMalloc(&d_dep, npix * 4)); CK(hipMalloc(&d_st, 256));
+    const size_t st_bytes = getenv("KB_STAMPS") ? (64 + 3 * 65536) * 4 : 256;   // KB_STAMPS=1 (with GMPI_TUNE_WAVE=16384 on a profiling build): room for per-workgroup time stamps
+    CK(hipMalloc(&d_ray, ray.size() * 4)); CK(hipMalloc(&d_rgb, npix * 3 * 4)); CK(hipMalloc(&d_dep, npix * 4)); CK(hipMalloc(&d_st, st_bytes)); CK(hipMemset(d_st, 0, st_bytes));
     CK(hipMemcpy(d_dhw, dhw.data(), dhw.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_eye, eye.data(), eye.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_zd, zd.data(), zd.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ray, ray.data(), ray.size() * 4, hipMemcpyHostToDevice));
     const size_t chan = (size_t)S * S, plane = 4 * chan;
@@ -124,6 +125,18 @@ int main(int argc, char** argv) {
         for (int i = 0; i < reps; ++i) {
             CK(hipEventRecord(e0)); launch(&p, nullptr); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best; sum += ms;
+        }
+        if (getenv("KB_STAMPS")) {   // per XCD: when its workgroups of the LAST launch started and ended (s_memtime: 100 MHz)
+            std::vector<uint32_t> stv(64 + 3 * 65536);
+            CK(hipMemcpy(stv.data(), d_st, stv.size() * 4, hipMemcpyDeviceToHost));
+            uint32_t t0 = 0xffffffffu, t1 = 0; int nwg = 0;
+            for (int b = 0; b < 65536; ++b) { const uint32_t a = stv[64 + 3 * b], e = stv[65 + 3 * b]; if (e == 0) continue; ++nwg; if (a < t0) t0 = a; if (e > t1) t1 = e; }
+            printf("  stamps: %d workgroups, launch span %.1f us\n", nwg, (t1 - t0) * 0.01);
+            for (int x = 0; x < 8; ++x) {
+                uint32_t last = 0, first_end = 0xffffffffu; int cnt = 0, by_block = 0; double busy = 0;
+                for (int b = 0; b < 65536; ++b) { const uint32_t a = stv[64 + 3 * b], e = stv[65 + 3 * b]; if (e == 0 || (int)stv[66 + 3 * b] != x) continue; ++cnt; by_block += (b % 8 == x); if (e > last) last = e; if (e < first_end) first_end = e; busy += (e - a) * 0.01; }
+                if (cnt) printf("    XCC %d: %4d workgroups (%4d with blockIdx %% 8 == XCC), last ends at %8.1f us, mean workgroup life %7.1f us, sum of lives / 64 slots %8.1f us\n", x, cnt, by_block, (last - t0) * 0.01, busy / cnt, busy / 64);
+            }
         }
         double dc = 0, dd = 0; size_t nan = 0;
         if (ref_rgb.empty()) ref_rgb = rgb, ref_dep = dep;
