@@ -273,7 +273,7 @@ static int to_kparams(const GmpiRenderParams* q, KParams& p, bool need_outputs, 
     p.ws = q->workspace;
     p.ws_bytes = q->workspace != nullptr ? q->workspace_bytes : 0;
     p.gate = nullptr, p.gate_gen = 0, p.gate_sense = 0;
-    p.band_cols = 1, p.band_rot = 0;
+    p.band_cols = 1, p.band_rot = 0, p.band_split = 1, p.band_tail = 0;
     return GMPI_OK;
 }
 

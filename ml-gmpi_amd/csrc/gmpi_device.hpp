@@ -42,7 +42,8 @@ struct KParams {
     uint32_t* gate;
     uint32_t gate_gen, gate_sense;
     int32_t band_cols;  // band kernel: band columns per XCD window (render_band.hip band_pos; set by launch_band)
-    int32_t band_rot;   // band kernel: per-view rotation of the XCD <-> run assignment (xcd_item_per_group)
+    int32_t band_rot, band_split;   // band kernel: per-view rotation of the XCD <-> run assignment, pieces per run (xcd_item_per_group)
+    int32_t band_tail;              // band kernel: the last band_tail bands of every XCD's last run are handed out by tickets (render_band.hip)
 };
 
 // blockIdx -> work item (pixel tile / band), "per view group" form: XCD x = blockIdx % 8 (workgroups are dealt round-robin to the 8 XCDs)
@@ -52,10 +53,13 @@ struct KParams {
 // between XCDs afterwards: a launch ends when the most loaded XCD is done.  With rot = 0 every XCD renders the same region of every view; regions differ in
 // cost (the camera's keystone makes the texel boxes of some band rows taller: a third DMA pass), and what is expensive in one view tends to be expensive in the
 // next: rotating the assignment per view averages that out (round 6, render_band.hip; measured per XCD with s_memtime stamps: profiles/r06_band_order.txt).
-__device__ __forceinline__ int xcd_item_per_group(int block, int group_items, int n_items, int rot = 0) {
+// `split` (1, 2, 4 or 8): an XCD's run of a group is cut into `split` pieces taken from regions 8 / split apart (piece s from region + s 8 / split): the XCD then
+// renders pieces of opposite parts of the view -- whose costs complement each other -- already within ONE view.
+__device__ __forceinline__ int xcd_item_per_group(int block, int group_items, int n_items, int rot = 0, int split = 1) {
     const int per_xcd = (group_items + 7) / 8, n_groups = (n_items + group_items - 1) / group_items;
     const int jb = block / 8, grp = jb / per_xcd, rr = jb - grp * per_xcd;
-    const int in_group = ((block + grp * rot) % 8) * per_xcd + rr;
+    const int piece = split > 1 ? rr * split / per_xcd : 0;
+    const int in_group = ((block + grp * rot + piece * (8 / max(split, 1))) % 8) * per_xcd + rr;
     const int item = grp * group_items + in_group;
     return (grp >= n_groups || in_group >= group_items || item >= n_items) ? n_items : item;
 }

@@ -50,6 +50,13 @@ constexpr int kWindowCols16 = 2, kWindowCols32 = 2, kWindowCols32Deep = 1, kDeep
 // assignment by one XCD per view: config 3 bf16 0.7982 -> 0.7743 ms (-3.0 %) and 0.7856 -> 0.7676 (-2.3 %) on two boxes, four / three alternating repeats; fp32 -1.2 % / -0.8 %;
 // config 5 -0.3 % / -1 %; a rotation by 3 is as good on 16-bit volumes and worse on config 5 (profiles/r06_band_order.txt).
 constexpr int kViewRotation = 1;
+// ... each XCD's run of a view cut into two pieces from opposite regions of the view (xcd_item_per_group `split`): what is expensive at one end of a view tends to be cheap at
+// the other -- config 3 bf16 -0.9...-1.2 %, fp32 -0.4...-0.8 %, config 5 -0.2...-0.6 % on top of the rotation (two boxes, three / four alternating repeats; 4 or 8 pieces: no better).
+constexpr int kRunPieces = 2;
+// ... and the last bands of every XCD's last run handed out by tickets (see the kernel): -1 % on one box, nothing on another for the bench's pose draw (what is left after the
+// rotation is mostly silicon: even and odd XCDs differ by ~4 % per band on some boxes), -13 % when a launch's bands differ a lot (explicit GMPI_VARIANT_BAND with bands on the
+// direct-gather path); 64 per XCD is too many (+1 %: a stolen band's texels come from another XCD's neighbourhood).
+constexpr int kTicketTail = 16;
 constexpr float kCoordLimit = 16384.0f;
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -230,7 +237,7 @@ __device__ __forceinline__ Shape shape_unpack(uint32_t w) {
 }
 template <typename TexT, bool AC>
 __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
-                                                         uint4* __restrict__ recs, uint4* __restrict__ pl, uint32_t* __restrict__ hdr) {
+                                                         uint4* __restrict__ recs, uint4* __restrict__ pl, uint32_t* __restrict__ hdr, uint32_t* __restrict__ tickets) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kMaxRows = G::kMaxRows, kRowBytes = G::kRowBytes, kSubBytes = G::kSubBytes;
     constexpr int NSB = G::NSB;
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const
             r[1] = make_uint4(__float_as_uint(1.0f / hh), 0u, 0u, 0u);
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x < 8) tickets[threadIdx.x] = 0u;   // (the render kernel's ticket queues: one per XCD)
     const int any_unfit = __syncthreads_or(unfit ? 1 : 0);
     if (threadIdx.x == 0) {
         hdr[band_id] = static_cast<uint32_t>(any_unfit);
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const
 
 template <typename TexT, bool AC, bool STRICT, bool CHECK>
 __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void render_band_kernel(const KParams p, const int bands_x, const int bands_y, const int n_bands, const float cx, const float cy,
-                                                         const uint4* __restrict__ recs, const uint4* __restrict__ pl, const uint32_t* __restrict__ hdr) {
+                                                         const uint4* __restrict__ recs, const uint4* __restrict__ pl, const uint32_t* __restrict__ hdr, uint32_t* __restrict__ tickets) {
     using G = Geo<TexT>;
     constexpr int kES = G::kES, kTPI = G::kTPI, kCols = G::kCols, kNP = G::kNP;
     constexpr int NSB = G::NSB, PPT = G::PPT, WPS = G::WPS, kSubLanes = G::kSubLanes;
@@ -332,7 +340,40 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     // ---- blockIdx -> band.  XCD x = blockIdx % 8 gets a contiguous run of the bands of EVERY view (group of views that share an MPI): neighbours
     //      (column-major since round 5, see below) share halo rows in one L2, and the XCDs walk the views together (measured 4 % faster than one run of all bands per XCD,
     //      where different XCDs read different views at the same time) ----
-    int band_id = xcd_item_per_group(blockIdx.x, bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands, p.band_rot);
+    const int group_items = bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1);
+    int band_id;
+    {
+        // The tail of the launch is handed out by TICKETS (round 6).  The dispatcher deals workgroups to the XCDs round-robin by index and nothing moves between XCDs
+        // afterwards, so the launch ends when the slowest XCD -- the one whose regions cost most, or simply the slower silicon: even and odd XCDs differ by ~4 % in the
+        // time a band takes on the boxes measured -- has worked off its share.  The last p.band_tail bands of every XCD's LAST run are therefore not tied to a block index:
+        // the blocks that would have rendered them, plus as many EXTRA blocks per XCD appended to the grid, each draw a ticket -- from their own XCD's queue first (the
+        // same bands in the same order as the static assignment), then from the others'.  An XCD that is done early finds its queue empty and takes what a late XCD has
+        // not started yet; a block that finds every queue empty leaves.  Every band is drawn exactly once (one atomic per queue and block, for the tail blocks only).
+        const int per_xcd = (group_items + 7) / 8, n_groups = (n_bands + group_items - 1) / group_items, static_blocks = per_xcd * 8 * n_groups;
+        const int T = min(p.band_tail, per_xcd);
+        const int jb = static_cast<int>(blockIdx.x) / 8, x = static_cast<int>(blockIdx.x) % 8;
+        const bool ticketed = T > 0 && (static_cast<int>(blockIdx.x) >= static_blocks || (jb / per_xcd == n_groups - 1 && jb % per_xcd >= per_xcd - T));
+        if (!ticketed) {
+            band_id = blockIdx.x < static_cast<unsigned>(static_blocks) ? xcd_item_per_group(blockIdx.x, group_items, n_bands, p.band_rot, p.band_split) : n_bands;
+        } else {
+            int* word = reinterpret_cast<int*>(smem + 2 * kBufBytes);   // (the loader-offset area: written further down, behind a barrier)
+            if (threadIdx.x == 0) {
+                int got = n_bands;
+                for (int i = 0; i < 8; ++i) {
+                    const int q = (x + i) % 8;
+                    const int t = static_cast<int>(atomicAdd(tickets + q, 1u));
+                    if (t < T) {   // queue q, ticket t = the block (q, last group, position per_xcd - T + t) of the static assignment
+                        got = xcd_item_per_group(q + 8 * ((n_groups - 1) * per_xcd + per_xcd - T + t), group_items, n_bands, p.band_rot, p.band_split);
+                        break;
+                    }
+                }
+                *word = got;
+            }
+            __syncthreads();
+            band_id = __builtin_amdgcn_readfirstlane(*word);
+            __syncthreads();   // (everybody has read the word before the loader offsets overwrite it)
+        }
+    }
 #ifdef GMPI_TUNE  // (experiment: one contiguous run of ALL bands per XCD)
     if (p.flags & (1u << 19)) band_id = static_cast<int>(blockIdx.x % 8) * ((n_bands + 7) / 8) + static_cast<int>(blockIdx.x / 8);
 #endif
@@ -901,9 +942,9 @@ static void band_grid(const KParams& p, int nsb, int& bands_x, int& bands_y, int
     bands_x = (p.W + nsb * SBW - 1) / (nsb * SBW), bands_y = (p.H + SBH - 1) / SBH;
     n_bands = bands_x * bands_y * p.N;
 }
-// workspace: [n_bands] header words + [N] view gate words | (N * D + 2) plane records of 32 bytes | (n_bands * D + 2) * NSB box records of 16 bytes (each part 256-aligned)
+// workspace: [n_bands] header words + [N] view gate words + 8 ticket counters | (N * D + 2) plane records of 32 bytes | (n_bands * D + 2) * NSB box records of 16 bytes (each part 256-aligned)
 static uint64_t align256(uint64_t v) { return (v + 255) / 256 * 256; }
-static uint64_t ws_hdr_bytes(int n_bands, int n_views) { return align256((static_cast<uint64_t>(n_bands) + n_views) * 4); }
+static uint64_t ws_hdr_bytes(int n_bands, int n_views) { return align256((static_cast<uint64_t>(n_bands) + n_views + 8) * 4); }   // header words | view gate words | 8 ticket counters
 static uint64_t ws_pl_bytes(const KParams& p) { return align256((static_cast<uint64_t>(p.N) * p.D + 2) * kPlU4 * 16); }
 static uint64_t ws_bytes(const KParams& p, int nsb) {
     int bx, by, nb;
@@ -916,7 +957,10 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
     constexpr int NSB = Geo<TexT>::NSB;
     int bands_x, bands_y, n_bands;
     band_grid(p, NSB, bands_x, bands_y, n_bands);
-    const dim3 grid(xcd_grid_per_group(bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_bands)), block(Geo<TexT>::kThreads);
+    const int group_items = bands_x * bands_y * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1);
+    const int tail = std::min(p.band_tail, (group_items + 7) / 8);
+    const dim3 grid(xcd_grid_per_group(group_items, n_bands) + 8u * static_cast<unsigned>(tail)), block(Geo<TexT>::kThreads);   // (+ the extra blocks that only draw tickets)
+    uint32_t* tickets = static_cast<uint32_t*>(p.ws) + n_bands + p.N;
     const bool acf = p.flags & 1u;
     const float cx = acf ? static_cast<float>(p.Wt - 1) * 0.5f : static_cast<float>(p.Wt), cy = acf ? static_cast<float>(p.Ht - 1) * 0.5f : static_cast<float>(p.Ht);
     uint32_t* hdr = static_cast<uint32_t*>(p.ws);
@@ -925,13 +969,13 @@ static hipError_t launch_t(const KParams& p, hipStream_t stream) {
     // 1. the geometry table (one workgroup per band; writes every word the render kernel reads but the two planes of padding, whose content
     //    is never used)
     const dim3 tgrid(static_cast<unsigned>(n_bands)), tblock(static_cast<unsigned>(std::min(1024, (p.D * NSB + 63) / 64 * 64)));  // one record per thread up to 256 planes
-    if (acf) hipLaunchKernelGGL((band_table_kernel<TexT, true>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr);
-    else hipLaunchKernelGGL((band_table_kernel<TexT, false>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr);
+    if (acf) hipLaunchKernelGGL((band_table_kernel<TexT, true>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr, tickets);
+    else hipLaunchKernelGGL((band_table_kernel<TexT, false>), tgrid, tblock, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr, tickets);
     // 2. the render
     const int sel = (p.flags & 1u ? 4 : 0) | (p.flags & (1u << 4) ? 2 : 0) | (p.flags & (1u << 3) ? 1 : 0);  // align_corners, strict order, range check
     switch (sel) {
 #define GMPI_BAND_CASE(I, AC_, ST_, CK_) \
-    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr); break;
+    case I: hipLaunchKernelGGL((render_band_kernel<TexT, AC_, ST_, CK_>), grid, block, 0, stream, p, bands_x, bands_y, n_bands, cx, cy, recs, pl, hdr, tickets); break;
         GMPI_BAND_CASE(0, false, false, false) GMPI_BAND_CASE(1, false, false, true) GMPI_BAND_CASE(2, false, true, false) GMPI_BAND_CASE(3, false, true, true)
         GMPI_BAND_CASE(4, true, false, false) GMPI_BAND_CASE(5, true, false, true) GMPI_BAND_CASE(6, true, true, false) GMPI_BAND_CASE(7, true, true, true)
 #undef GMPI_BAND_CASE
@@ -970,13 +1014,17 @@ bool band_variant_supports(const KParams& p, int dtype) {
 hipError_t launch_band(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
     p.band_cols = dtype != 0 ? band::kWindowCols16 : p.D > band::kDeepPlanes ? band::kWindowCols32Deep : band::kWindowCols32;
-    p.band_rot = band::kViewRotation;
+    p.band_rot = band::kViewRotation, p.band_split = band::kRunPieces, p.band_tail = band::kTicketTail;
 #ifdef GMPI_TUNE  // profiling builds: tune bits 8-9 = ablations (no memory traffic / no compositing); GMPI_TUNE_ORDER = band columns per XCD window
     p.flags |= static_cast<uint32_t>((tune >> 8) & 127) << 16;
     static const int env_order = [] { const char* e = getenv("GMPI_TUNE_ORDER"); return e ? atoi(e) : 0; }();
     if (env_order > 0) p.band_cols = env_order;
     static const int env_rot = [] { const char* e = getenv("GMPI_TUNE_ROT"); return e ? atoi(e) : -1; }();
     if (env_rot >= 0) p.band_rot = env_rot;
+    static const int env_split = [] { const char* e = getenv("GMPI_TUNE_SPLIT"); return e ? atoi(e) : 0; }();
+    if (env_split > 0) p.band_split = env_split;
+    static const int env_tail = [] { const char* e = getenv("GMPI_TUNE_TAIL"); return e ? atoi(e) : -1; }();
+    if (env_tail >= 0) p.band_tail = env_tail;
 #else
     (void)tune;
 #endif
