@@ -40,6 +40,8 @@
 // of tiles).  Algorithmic bytes: 16 B (fp32) / 8 B (bf16) per pixel*plane + 28-32 B per pixel.
 #include "gmpi_device.hpp"
 
+#include <cstdlib>
+
 #include <algorithm>
 
 #include <type_traits>
@@ -177,7 +179,7 @@ __device__ __forceinline__ void render_lds_tile(const KParams& p, const int tile
     //  * fp32 volumes: measured 1.5 % (config 3 shape) to 3.7 % (config 5) faster than one run per XCD, 16-bit volumes 1 % slower
     //    (profiles/r03_xcd_order.txt) -- so 16-bit volumes keep the run per XCD.
     if (p.gate != nullptr || sizeof(TexT) == 4)
-        tile_id = xcd_item_per_group(vblock, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles);
+        tile_id = xcd_item_per_group(vblock, tiles_per_view * (p.view_to_mpi == nullptr ? p.views_per_mpi : 1), n_tiles, p.band_rot, p.band_split);
 #ifdef GMPI_TUNE  // (experiment: flag bit 19 flips the order)
     if (p.flags & (1u << 19)) {
         tile_id = (p.gate != nullptr || sizeof(TexT) == 4) ? (vblock % 8) * per_xcd + vblock / 8
@@ -705,10 +707,19 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+constexpr int kTileViewRotation = 1, kTileRunPieces = 2;   // (as the band kernel: profiles/r06_band_order.txt -- config 3 fp32 on the tile kernel 1.324 -> 1.309 ms, config 4 and tilted sets unchanged)
+
 hipError_t launch_lds(const KParams& p0, int dtype, int tune, hipStream_t stream) {
     KParams p = p0;
+    p.band_rot = kTileViewRotation, p.band_split = kTileRunPieces;   // (the XCD <-> tile-run assignment of the per-group order: gmpi_device.hpp xcd_item_per_group)
 #ifdef GMPI_TUNE  // profiling builds: GMPI_TUNE_WAVE + 256 no memory traffic, + 512 no compositing (loader only), + 1024 no LDS stores
     p.flags |= static_cast<uint32_t>((tune >> 8) & 15) << 16;
+    {
+        static const int env_rot = [] { const char* e = getenv("GMPI_TUNE_ROT"); return e ? atoi(e) : -1; }();
+        static const int env_split = [] { const char* e = getenv("GMPI_TUNE_SPLIT"); return e ? atoi(e) : 0; }();
+        if (env_rot >= 0) p.band_rot = env_rot;
+        if (env_split > 0) p.band_split = env_split;
+    }
 #endif
     // Shipped instances only: fp32 volumes keep fp32 planes in LDS (LAYOUT 0, 3 workgroups per CU), 16-bit volumes their raw
     // texels, interleaved (LAYOUT 1, 4 workgroups per CU); 32x16 pixel tiles, one plane of prefetch -- the values the round-1

@@ -74,7 +74,8 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
 
     GmpiRenderParams p; memset(&p, 0, sizeof p);
-    p.struct_size = sizeof p; p.rgba_dtype = dt; p.N = N; p.M = N; p.D = D; p.Ht = p.Wt = p.H = p.W = S; p.views_per_mpi = 1;
+    const int vpm = getenv("KB_VPM") ? atoi(getenv("KB_VPM")) : 1;   // KB_VPM=8: the views share MPIs in groups of 8 (config 4: a camera path over ONE MPI)
+    p.struct_size = sizeof p; p.rgba_dtype = dt; p.N = N; p.M = (N + vpm - 1) / vpm; p.D = D; p.Ht = p.Wt = p.H = p.W = S; p.views_per_mpi = vpm;
     p.rgba = vol; p.rgba_stride[0] = (int64_t)D * plane; p.rgba_stride[1] = plane; p.rgba_stride[2] = chan; p.rgba_stride[3] = S; p.rgba_stride[4] = 1;
     p.dhw = d_dhw; p.ray_dir = d_ray; p.eye_pos = d_eye; p.z_dir = d_zd; p.rgb_out = d_rgb; p.depth_out = d_dep; p.status = d_st;
     if (getenv("KB_PLANE_STRIDE0")) p.rgba_stride[1] = 0;  // (ablation: every plane reads plane 0 -- the volume becomes cache resident, the byte counts stay)

@@ -75,3 +75,11 @@ r = MPIRenderer(**kw)
 r.set_cam(r.cam_fov, 1024, 1024)
 torch.manual_seed(3)
 dump("b256", r.sample_cam_poses(4, r.horizontal_mean, r.horizontal_std, r.vertical_mean, r.vertical_std, True))
+
+# config 4: 8 camera-path views of ONE 512^2 x 96 MPI (yaw sweep 0.5 ... -0.5, pitch 0: render_video.py:236-237); run with KB_VPM=8
+kw = dict(PRESETS["FFHQ"])
+kw.update(n_mpi_planes=96, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse", cam_sample_method="truncated_gaussian",
+          mpi_align_corners=True, use_confined_volume=True, device=torch.device("cpu"))
+r = MPIRenderer(**kw)
+r.set_cam(r.cam_fov, 512, 512)
+dump("c4", r.sample_cam_poses(8, 0, 0, 0, 0, False, given_yaws=torch.linspace(0.5, -0.5, 8).view(-1, 1), given_pitches=torch.zeros(8, 1)))
