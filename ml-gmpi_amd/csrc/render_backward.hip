@@ -338,6 +338,10 @@ __global__ __launch_bounds__(kB2Threads, 6) void render_backward_tile2_kernel(co
     __shared__ float2 pcB[kB2Chunk];      // RN(2/h), headroom bits (as int bits)
     __shared__ uint32_t gmax[kB2Chunk];   // per plane: largest |sample gradient| of the tile, as fp32 bits
     __shared__ uint32_t acc[2][kB2Cap];
+#ifdef GMPI_B2_PAD  // (experiment: LDS nobody uses, to hold the workgroups per CU down)
+    __shared__ uint32_t lds_pad[GMPI_B2_PAD / 4];
+    lds_pad[threadIdx.x] = 0u;
+#endif
     constexpr int kES = static_cast<int>(sizeof(TexT));
     const int tid = threadIdx.x;
     // the role of a WAVE (kB2Pix is a multiple of 64), as a scalar: the two roles run separate loop nests behind a scalar branch -- as

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
 #ifdef GMPI_TUNE  // GMPI_TUNE_WAVE + 16384: every workgroup leaves (start, end, XCC id) in status[64 + 3 blockIdx ...] (tools/kbench KB_STAMPS=1: who finishes when, per XCD)
     const bool stamp = (p.flags & (1u << 22)) != 0 && p.status != nullptr;
     uint64_t stamp_start = 0;
-    if (stamp) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_start));
+    if (stamp) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_start));   // (the 100 MHz reference clock: ONE epoch for the device; s_memtime counts per XCC / shader engine)
 #endif
 
     const int tid = threadIdx.x;
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(Geo<TexT>::kThreads, Geo<TexT>::kWavesPerSimd) void
     if (stamp && threadIdx.x == 0) {
         uint64_t stamp_end;
         uint32_t xcc;
-        asm volatile("s_memtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_end), "=s"(xcc));
+        asm volatile("s_memrealtime %0\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_end), "=s"(xcc));
         p.status[64 + 3 * blockIdx.x] = static_cast<uint32_t>(stamp_start), p.status[65 + 3 * blockIdx.x] = static_cast<uint32_t>(stamp_end), p.status[66 + 3 * blockIdx.x] = xcc & 15u;
     }
 #endif

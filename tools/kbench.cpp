@@ -44,14 +44,15 @@ int main(int argc, char** argv) {
     if (!f) { printf("no input set %s\n", set.c_str()); return 1; }
     int hdr[3];
     if (fread(hdr, 4, 3, f) != 3) return 1;
-    const int N = (argc > 6 && atoi(argv[6]) > 0 && atoi(argv[6]) < hdr[0]) ? atoi(argv[6]) : hdr[0], S = hdr[1], Dfile = hdr[2];  // [views]: the first n of the set
+    const int krep = getenv("KB_REPEAT") ? atoi(getenv("KB_REPEAT")) : 1;   // KB_REPEAT=k: the set's views k times over (more rounds of workgroups per launch, the same cameras)
+    const int N = ((argc > 6 && atoi(argv[6]) > 0 && atoi(argv[6]) < hdr[0]) ? atoi(argv[6]) : hdr[0]) * krep, S = hdr[1], Dfile = hdr[2];  // [views]: the first n of the set
     const int D = (argc > 7 && atoi(argv[7]) > 0 && atoi(argv[7]) < Dfile) ? atoi(argv[7]) : Dfile;  // [planes]: the nearest d of the set
     float focal;
     std::vector<float> dhw1(Dfile * 3), c2w(hdr[0] * 16), eye(N * 3), zd(N * 3), ray((size_t)N * 3 * S * S);
     if (fread(&focal, 4, 1, f) != 1 || fread(dhw1.data(), 4, dhw1.size(), f) != dhw1.size() || fread(c2w.data(), 4, c2w.size(), f) != c2w.size()) { printf("short file\n"); return 1; }
     fclose(f);
     for (int n = 0; n < N; ++n) {  // camera.py:98-118, 182-211: K^-1 [x + .5, y + .5, 1] normalised (float64), cast, rotated
-        const float* M = &c2w[n * 16];
+        const float* M = &c2w[(n % (N / krep)) * 16];
         for (int c = 0; c < 3; ++c) eye[n * 3 + c] = M[c * 4 + 3], zd[n * 3 + c] = M[c * 4 + 2];
         for (int y = 0; y < S; ++y)
             for (int x = 0; x < S; ++x) {
@@ -134,9 +135,14 @@ int main(int argc, char** argv) {
             for (int b = 0; b < 65536; ++b) { const uint32_t a = stv[64 + 3 * b], e = stv[65 + 3 * b]; if (e == 0) continue; ++nwg; if (a < t0) t0 = a; if (e > t1) t1 = e; }
             printf("  stamps: %d workgroups, launch span %.1f us\n", nwg, (t1 - t0) * 0.01);
             for (int x = 0; x < 8; ++x) {
-                uint32_t last = 0, first_end = 0xffffffffu; int cnt = 0, by_block = 0; double busy = 0;
-                for (int b = 0; b < 65536; ++b) { const uint32_t a = stv[64 + 3 * b], e = stv[65 + 3 * b]; if (e == 0 || (int)stv[66 + 3 * b] != x) continue; ++cnt; by_block += (b % 8 == x); if (e > last) last = e; if (e < first_end) first_end = e; busy += (e - a) * 0.01; }
-                if (cnt) printf("    XCC %d: %4d workgroups (%4d with blockIdx %% 8 == XCC), last ends at %8.1f us, mean workgroup life %7.1f us, sum of lives / 64 slots %8.1f us\n", x, cnt, by_block, (last - t0) * 0.01, busy / cnt, busy / 64);
+                uint32_t last = 0, first = 0xffffffffu; int cnt = 0, by_block = 0; double busy = 0;
+                for (int b = 0; b < 65536; ++b) { const uint32_t a = stv[64 + 3 * b], e = stv[65 + 3 * b]; if (e == 0 || (int)stv[66 + 3 * b] != x) continue; ++cnt; by_block += (b % 8 == x); if (e > last) last = e; if (a < first) first = a; busy += (e - a) * 0.01; }
+                if (!cnt) continue;
+                // (the stamps of one XCC share an epoch: its own span = first start ... last end; how full its 64 slots were over that span; how many slots still ran 2 / 5 / 10 % before its end)
+                const double span = (last - first) * 0.01; int run2 = 0, run5 = 0, run10 = 0;
+                for (int b = 0; b < 65536; ++b) { const uint32_t a = stv[64 + 3 * b], e = stv[65 + 3 * b]; if (e == 0 || (int)stv[66 + 3 * b] != x) continue;
+                    const double ta = (a - first) * 0.01, te = (e - first) * 0.01; run2 += ta <= 0.98 * span && te > 0.98 * span; run5 += ta <= 0.95 * span && te > 0.95 * span; run10 += ta <= 0.9 * span && te > 0.9 * span; }
+                printf("    XCC %d: %4d workgroups (%4d with blockIdx %% 8 == XCC), span %8.1f, mean workgroup life %7.1f, sum of lives / 64 slots %8.1f = %.3f of the span; slots busy at 90 / 95 / 98 %% of the span: %d %d %d\n", x, cnt, by_block, span, busy / cnt, busy / 64, busy / 64 / span, run10, run5, run2);
             }
         }
         double dc = 0, dd = 0; size_t nan = 0;
