@@ -91,3 +91,48 @@ def test_render_launch_replays_from_a_graph(dtype, strict):
             orc = oracle.render(rgba0.to(dtype).float(), *sets[0], threads=True)
             for k in ("color", "depth", "T"):
                 assert np.array_equal(got[k], orc[k]), k
+
+
+def test_forward_and_backward_replay_from_a_graph():
+    """The G-step's render (train.py:740-779: forward, then d/d rgba through the autograd bridge) recorded as ONE graph and replayed over a new volume:
+    colour bit-identical to the uncaptured step, the gradient to the atomics' order (1e-6 of its largest element).  Every step, the first included, runs on
+    the capture stream: a leaf whose first backward ran on another stream makes torch's engine tie the two streams together, which ends a capture."""
+    from ml_gmpi_amd import MPI
+    dev = torch.device("cuda:0")
+    S, B, D = 256, 4, 8
+    rgba0, dhw, ray, eye, zd = _random_case(seed=81, B=B, D=D, S=S)
+    rgba1 = _random_case(seed=82, B=B, D=D, S=S)[0]
+    mpi = MPI(align_corners=True, variant="auto", range_check="touched", on_out_of_plane="raise")
+    dhw, ray, eye, zd = (t.to(dev) for t in (dhw, ray, eye, zd))
+    g = torch.Generator(device=dev).manual_seed(83)
+    gc, gd = torch.randn((B, 3, S, S), device=dev, generator=g), torch.randn((B, 1, S, S), device=dev, generator=g)
+    status = torch.zeros(_lib().STATUS_WORDS, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        vol = rgba0.to(dev).clone().requires_grad_(True)
+
+        def step():
+            res = mpi.render_views(vol, dhw, ray, eye, zd, views_per_mpi=1, check_last_plane=True, status=status, defer_status=True)
+            loss = (res["color"] * gc).sum() + (res["depth"] * gd).sum()
+            grad, = torch.autograd.grad(loss, vol)
+            return res["color"], grad
+
+        want = {}
+        for vi, volume in enumerate((rgba0, rgba1)):
+            with torch.no_grad():
+                vol.copy_(volume.to(dev))
+            c, gr = step()
+            torch.cuda.synchronize()
+            want[vi] = (c.clone(), gr.clone())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            c_out, g_out = step()
+        for vi in (0, 1, 0):
+            with torch.no_grad():
+                vol.copy_((rgba0, rgba1)[vi].to(dev))
+            graph.replay()
+            torch.cuda.synchronize()
+            assert int(status[0].item()) == 0
+            assert torch.equal(c_out, want[vi][0]), vi
+            assert float((g_out - want[vi][1]).abs().max() / want[vi][1].abs().max()) <= 1e-6, vi
