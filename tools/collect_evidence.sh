@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies what gpurun_in/r6_evidence.sh left under gpurun_out/ into profiles/ (tracked): tools/collect_evidence.sh r06
+# Copies what tools/evidence.sh left under gpurun_out/ into profiles/ (tracked): tools/collect_evidence.sh r06
 # (refuses when the traffic file was not measured on the sources of this tree)
 set -e
 cd "$(dirname "$0")/.."
