@@ -40,10 +40,11 @@ constexpr int SBW = 64, SBH = 8;       // sub-block: 64 x 8 pixels
 constexpr float kBoxEps = 1.0f / 64;
 // Band columns per XCD window (band_pos below), measured in round 6 (profiles/r06_band_order.txt: three boxes, alternating repeats, L2 -> fabric bytes
 // from FETCH_SIZE passes).  Two columns: config 3 (bf16) 0.7945 -> 0.7790 ms with 0.987 x instead of 1.074 x the algorithmic bytes crossing the L2s,
-// config 3 with an fp32 volume 1.170 -> 1.163 ms, 0.988 x instead of 1.081 x.  Deep fp32 stacks (config 5: 256 planes) are the exception: one column
-// is 1.5-4.6 % faster there although it moves more bytes (1.142 x against 1.079 x) -- not a channel or XCD imbalance (TCC_EA0_RDREQ / TCC_BUSY per
-// channel are flat to 0.1 % in every order), not the position in the run sequence, and box-dependent (one box of three shows no difference).
-constexpr int kWindowCols16 = 2, kWindowCols32 = 2, kWindowCols32Deep = 1, kDeepPlanes = 128;
+// config 3 with an fp32 volume 1.170 -> 1.163 ms, 0.988 x instead of 1.081 x.  Deep fp32 stacks (config 5: 256 planes) used to be the exception -- one
+// column was 1.5-4.6 % faster there although it moves more bytes (1.142 x against 1.075 x): with one column every XCD owns the full height of every view,
+// with two the top or the bottom half of a window, and a launch lasts as long as its busiest XCD (below).  Since an XCD's run comes in two pieces from
+// opposite regions (kRunPieces) that no longer holds: two columns are 0.1-1.7 % faster there too (two boxes, 3 + 6 alternating repeats), with 6 % fewer bytes.
+constexpr int kWindowCols16 = 2, kWindowCols32 = 2, kWindowCols32Deep = 2, kDeepPlanes = 128;
 // Per-view rotation of the XCD <-> run assignment (gmpi_device.hpp xcd_item_per_group; round 6).  Workgroups are dealt to the XCDs round-robin and stay there: a launch
 // ends when the most loaded XCD is done, and with every XCD rendering the SAME region of every view the regional cost differences (keystone: taller boxes, a third DMA
 // pass) add up over the views -- s_memtime stamps per workgroup (tools/kbench KB_STAMPS=1): the busiest XCD carries 3.6 % more than the mean on config 3.  Rotating the
