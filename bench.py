@@ -674,7 +674,7 @@ def pose_sweep(r, rgba, dhw, n_views, vpm, want_T, S, draws, out, status, seed0=
             e0.record(); step(); e1.record()
         torch.cuda.synchronize(dev)
         ms.append(statistics.median(e0.elapsed_time(e1) for e0, e1 in evs))
-        ws = next(iter(hip_mpi._WORKSPACES.values()), None) if hip_mpi._WORKSPACES else None
+        ws = hip_mpi.workspace_of(dev)
         if ws is not None and ws.numel() >= 4 * n_bands_view * n_views and r.mpi.variant == "auto":
             hdr = ws[:4 * n_bands_view * n_views].view(torch.int32).view(n_views, n_bands_view)
             off_band += int((hdr != 0).any(dim=1).sum())

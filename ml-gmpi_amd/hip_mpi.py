@@ -98,6 +98,14 @@ def _workspace(dev: torch.device, stream: int, need: int) -> torch.Tensor:
     return ws
 
 
+def workspace_of(dev: torch.device, stream: int = None):
+    """The scratch this module lends to launches on (device, stream) -- default: the current stream -- or None.  For tests and `bench.py`, which read
+    the band kernel's header words (which views the table kernel handed to the tile kernel) out of it after a launch."""
+    stream = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    with _CACHE_LOCK:
+        return _WORKSPACES.get(_stream_key(dev, stream))
+
+
 # Status words of calls that read them back themselves (status=None, defer_status=False): one tensor per device and stream, zero between
 # calls -- a call that finds a bit set clears the words before it raises -- instead of a fresh `torch.zeros` (an allocation and a fill
 # kernel in front of every render).

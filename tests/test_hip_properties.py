@@ -160,7 +160,7 @@ def test_config5_shape_auto_shares_the_views_between_band_and_tile_kernel():
     fast = run(r, rgba, dhw, ray, eye, zd, "auto", strict=False)
     torch.cuda.synchronize()
     n_bands_view = (S // 128) * (S // 8)      # fp32 volumes: bands of 128 x 8 pixels
-    ws = next(iter(hip_mpi._WORKSPACES.values()))
+    ws = hip_mpi.workspace_of(dev)   # (of THIS stream: other tests leave workspaces of their own streams in the cache)
     hdr = ws[:4 * n_bands_view * B].view(torch.int32).view(B, n_bands_view)
     assert (hdr != 0).any(dim=1).cpu().tolist() == [False, True, True]
     for v in range(B):   # (one view's volume on the host at a time: 4.3 GB)
