@@ -589,7 +589,7 @@ def pose_hints(zd):
     """The advisory flags MPIRenderer.render derives from the poses it has drawn (renderer.py: _COS_FRONTAL, _COS_TILTED)."""
     from ml_gmpi_amd import renderer as _r
     m = float(zd[:, 2].min())
-    return dict(frontal_hint=m >= _r._COS_FRONTAL, tilted_hint=m < _r._COS_TILTED)
+    return dict(frontal_hint=m >= _r._COS_FRONTAL, tilted_hint=m < _r._COS_TILTED, oblique_hint=m < _r._COS_OBLIQUE)
 
 
 PARITY_BAR = 1e-5  # BASELINE.json north_star: "within 1e-5 fp32" (colour on the [-1, 1] scale of MPIRenderer.render, depth in scene units)

@@ -73,7 +73,14 @@ enum {
                                             of grad_rgba (no zero-fill needed); without the flag it reads, adds and writes back.  On the tile-kernel
                                             path (no workspace, or a launch the gather path does not take) the flag changes nothing: that path only
                                             ever ADDS, and the caller zero-fills as before.                                                      */
-    GMPI_FLAG_ALL = (1 << 8) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
+    GMPI_FLAG_HINT_OBLIQUE = 1 << 8,     /* advisory (round 6), between the two: SOME view's camera axis is more than 0.35 rad off the MPI normal.  Only read for
+                                            launches whose views SHARE MPIs (views_per_mpi > 1: camera paths over one MPI): without it GMPI_VARIANT_AUTO renders
+                                            them with the band kernel -- 9 % (fp32) to 20 % (16-bit volumes) faster than the tile kernel when every view's texel
+                                            boxes fit its buffers, which cameras up to 0.35 rad do at 512^2 (and further out on larger images) -- and, when the device finds a view that does not
+                                            fit, hands that view's whole group of views to the tile kernel (a table kernel and an empty band launch, ~20 us, for
+                                            nothing); with it such launches go to the tile kernel at once, as in rounds 1-5.  GMPI_FLAG_HINT_TILTED implies it.
+                                            Never changes a result.                                                                                           */
+    GMPI_FLAG_ALL = (1 << 9) - 1         /* every defined bit; any other bit -> GMPI_E_FLAGS            */
 };
 
 /* bits of status[0] (OR-accumulated across launches until the caller clears the word) */

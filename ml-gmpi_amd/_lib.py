@@ -15,6 +15,7 @@ _LIB = None
 ABI_VERSION = 2
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 FLAG_ALIGN_CORNERS, FLAG_OUT_PM1, FLAG_CHECK_LAST_PLANE, FLAG_CHECK_RANGE, FLAG_STRICT_ORDER, FLAG_HINT_FRONTAL, FLAG_HINT_TILTED = 1, 2, 4, 8, 16, 32, 64
+FLAG_HINT_OBLIQUE = 256     # advisory: some camera axis more than 0.35 rad off the MPI normal (views that share an MPI then stay on the tile kernel)
 FLAG_GRAD_OVERWRITE = 128   # backward only: grad_rgba's content is not needed (with the backward's workspace every element is written: no zero-fill)
 STATUS_OUT_OF_LAST_PLANE, STATUS_RGBA_RANGE, STATUS_CAMERA_BEHIND_PLANE, STATUS_BAD_VIEW_INDEX = 1, 2, 4, 8
 STATUS_WORDS = 4

@@ -294,10 +294,19 @@ static int64_t band_count(const KParams& p, int dtype) {
 }
 static bool auto_takes_band(const KParams& p, int dtype) {
     if (dtype != GMPI_DTYPE_BF16 && dtype != GMPI_DTYPE_F32 && dtype != GMPI_DTYPE_F16) return false;
-    // Views that share one MPI (views_per_mpi > 1: the video paths) stay with the tile kernel: it interleaves them per tile so that the
-    // volume is read from HBM about once for the whole group (0.33x the algorithmic bytes on config 4) -- sharing the VIEWS out between two
-    // kernels would read it once per kernel (measured on config 4: 1.14 ms against 0.545).
-    if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) return false;
+    // Views that share one MPI (views_per_mpi > 1: the video paths).  Rounds 3-5 kept them on the tile kernel after a measurement -- config 4 through the band
+    // kernel + gate: 1.14 ms against 0.545 -- that was an artefact of the gated tile kernel's loop stride (kGatedGrid, render_lds.hip).  Both kernels interleave
+    // such views per band / tile position and read the volume from HBM about once per group; with every view fitting, the band kernel is faster: 8 views of one
+    // 512^2 x 96 MPI, yaw within +-0.25 rad: 0.521 -> 0.474 ms (fp32), 0.427 -> 0.340 (bf16); +-0.35: 0.528 -> 0.495, 0.427 -> 0.346.  A group with a view that
+    // does NOT fit goes to the tile kernel as a whole (the table kernel gates every view of the group: two small tile launches next to a thinned band launch
+    // lose, 0.78 against 0.545) -- which a caller that knows its cameras spares the launch by saying so (GMPI_FLAG_HINT_OBLIQUE / _TILTED).
+    if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) {
+        if ((p.flags & (GMPI_FLAG_HINT_OBLIQUE | GMPI_FLAG_HINT_TILTED)) != 0) return false;
+#ifdef GMPI_TUNE
+        static const int env_shared = [] { const char* e = getenv("GMPI_TUNE_SHARED"); return e ? atoi(e) : 1; }();   // (0: the old routing, for A/B runs)
+        if (env_shared == 0) return false;
+#endif
+    }
     const int bw = band_pixels_wide(dtype);
     const int64_t cols = (p.W + bw - 1) / bw, rows = (p.H + 7) / 8;
     // (an image that fills less than 3/4 of its bands -- narrower than a band, a ragged last column -- wastes the idle lanes' issue slots:

@@ -314,7 +314,14 @@ __global__ __launch_bounds__(1024) void band_table_kernel(const KParams p, const
     const int any_unfit = __syncthreads_or(unfit ? 1 : 0);
     if (threadIdx.x == 0) {
         hdr[band_id] = static_cast<uint32_t>(any_unfit);
-        if (any_unfit && p.gate != nullptr) p.gate[n] = p.gate_gen;  // (AUTO: the whole view goes to the tile kernel; gmpi_device.hpp)
+        if (any_unfit && p.gate != nullptr) {   // AUTO: the whole view goes to the tile kernel (gmpi_device.hpp) ...
+            if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) {   // ... and with it the views that share its MPI: the group stays together in ONE kernel, whose
+                const int first = n / p.views_per_mpi * p.views_per_mpi, size = min(p.views_per_mpi, p.N - first);   // interleaved order reads the volume once for all of them
+                for (int v = 0; v < size; ++v) p.gate[first + v] = p.gate_gen;
+            } else {
+                p.gate[n] = p.gate_gen;
+            }
+        }
     }
 }
 

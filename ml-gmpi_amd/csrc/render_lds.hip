@@ -148,7 +148,7 @@ __device__ __forceinline__ bool quad_out_of_unit(const float4& q) {
 // loop over a small grid (render_lds_gated_kernel).
 template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF, int LAYOUT>
 __device__ __forceinline__ void render_lds_tile(const KParams& p, const int tiles_x, const int tiles_y, const int n_tiles, const unsigned vblock,
-                                                const unsigned char* view_in = nullptr) {  // view_in: the gate, per view, already in LDS
+                                                const uint32_t* view_bits = nullptr) {  // view_bits: the gate, one bit per view, already in LDS
     using Q = Quad<TexT>;
     constexpr int LPR = LAYOUT == 1 ? 1 : 4;
     constexpr int kTexelBytes = 4 * static_cast<int>(sizeof(TexT));  // interleaved layout: RGBA of one texel
@@ -202,7 +202,7 @@ __device__ __forceinline__ void render_lds_tile(const KParams& p, const int tile
         n = tile_id / tiles_per_view;
         trem = tile_id - n * tiles_per_view;
     }
-    if (view_in != nullptr ? !view_in[n] : view_gated_out(p, n)) return;  // (AUTO: this view is the band kernel's)
+    if (view_bits != nullptr ? ((view_bits[n >> 5] >> (n & 31)) & 1u) == 0u : view_gated_out(p, n)) return;  // (AUTO: this view is the band kernel's)
     const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
 
     const int tid = threadIdx.x;
@@ -635,24 +635,35 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
 
 // AUTO's fallback launch for the views the band kernel leaves (KParams::gate): usually NO view is left, and a grid of one workgroup per
 // tile of every view that only exits costs 17 us for BASELINE config 3 (8192 workgroups: the dispatch rate).  So the gated launch has a
-// fixed, small grid whose workgroups walk the virtual block indices with a stride: 2 us when there is nothing to do.
-constexpr unsigned kGatedGrid = 1024;
+// fixed, small grid whose workgroups walk the virtual block indices round by round: 2 us when there is nothing to do.
+// The grid (round 6; profiles/r06_band_order.txt): about ONE round of resident workgroups and a multiple of 8 (a workgroup's virtual blocks stay on its XCD)
+// whose eighth is ODD -- 4 workgroups per CU with 16-bit volumes: 8 x 127 = 1016; 3 per CU with fp32 volumes (53 KB of LDS each): 8 x 95 = 760 (768: +8 %,
+// 1016: +22 % -- the last 256 run alone in a second round).  Odd, because views that share an MPI are interleaved per tile position (8 views: view =
+// (vblock / 8) % 8): a stride of 8 x 128 showed a workgroup the SAME view on every round, and two views of eight left to this kernel were rendered by a quarter
+// of the workgroups, four tiles each (0.645 ms).  Rounds 3-5 launched 1024 for both AND kept a byte per view in LDS, which took the fp32 instances over a third
+// of a CU's LDS: two workgroups per CU, 29 % slower than the plain tile kernel on the same tiles (below).  (Handing the tiles out by tickets -- an atomic counter
+// per XCD -- was built and measured: 512 returning atomics per counter serialise at more than 1 us each: 1.27 ms for what the plain tile kernel does in 0.545.)
+template <typename TexT> constexpr unsigned gated_grid() { return sizeof(TexT) == 4 ? 760u : 1016u; }
+constexpr int kGatedViews = 512;   // views whose gate a workgroup caches in LDS (kNT threads read one gate word each)
 template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF, int LAYOUT>
 __global__ __launch_bounds__(kNT, MINW) void render_lds_gated_kernel(const KParams p, const int tiles_x, const int tiles_y, const int n_tiles,
                                                                      const unsigned n_vblocks) {
-    // the gate words once per workgroup (a global load per tile would cost more than the dispatch it saves); nothing to do: exit
-    __shared__ unsigned char view_in[kNT];
-    const bool cached = p.N <= kNT;
+    // the gate words once per workgroup (a global load per tile would cost more than the dispatch it saves); nothing to do: exit.  ONE BIT per view: the fp32
+    // instances stage 53 000 bytes per workgroup and three workgroups share a CU's 160 KB -- rounds 3-5 kept a BYTE per view here (512 bytes), which took the
+    // allocation over a third of the LDS: the gated kernel ran two workgroups per CU, 29 % slower than the plain tile kernel on the same tiles (0.706 against
+    // 0.548 ms for config 4's eight views, one tile per workgroup in both).
+    __shared__ uint32_t view_bits[kGatedViews / 32];
+    const bool cached = p.N <= kGatedViews;
     if (cached) {
-        bool mine = false;
-        if (static_cast<int>(threadIdx.x) < p.N) {
-            mine = !view_gated_out(p, static_cast<int>(threadIdx.x));
-            view_in[threadIdx.x] = mine ? 1 : 0;
-        }
-        if (!__syncthreads_or(mine ? 1 : 0)) return;
+        const bool mine = static_cast<int>(threadIdx.x) < p.N && !view_gated_out(p, static_cast<int>(threadIdx.x));
+        if (!__syncthreads_or(mine ? 1 : 0)) return;   // (the usual case: one load, one barrier)
+        if (threadIdx.x < kGatedViews / 32) view_bits[threadIdx.x] = 0u;
+        __syncthreads();
+        if (mine) atomicOr(&view_bits[threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+        __syncthreads();
     }
     for (unsigned vb = blockIdx.x; vb < n_vblocks; vb += gridDim.x) {
-        render_lds_tile<TexT, AC, STRICT, TW, MINW, PF, LAYOUT>(p, tiles_x, tiles_y, n_tiles, vb, cached ? view_in : nullptr);
+        render_lds_tile<TexT, AC, STRICT, TW, MINW, PF, LAYOUT>(p, tiles_x, tiles_y, n_tiles, vb, cached ? view_bits : nullptr);
         __syncthreads();  // the next tile reuses the staging buffers and the table
     }
 }
@@ -693,7 +704,12 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     const dim3 grid(grid_x), block(kNT);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
     if (p.gate != nullptr) {
-        const dim3 ggrid(std::min(grid_x, kGatedGrid));
+        unsigned gg = std::min(grid_x, gated_grid<TexT>());
+#ifdef GMPI_TUNE  // GMPI_TUNE_GGRID: the gated launch's grid (A/B)
+        static const int env_gg = [] { const char* e = getenv("GMPI_TUNE_GGRID"); return e ? atoi(e) : 0; }();
+        if (env_gg > 0) gg = std::min(grid_x, static_cast<unsigned>(env_gg));
+#endif
+        const dim3 ggrid(gg);
         if (ac && strict) hipLaunchKernelGGL((render_lds_gated_kernel<TexT, true, true, TW, MINW, PF, LAYOUT>), ggrid, block, 0, stream, p, tiles_x, tiles_y, n_tiles, grid_x);
         else if (ac) hipLaunchKernelGGL((render_lds_gated_kernel<TexT, true, false, TW, MINW, PF, LAYOUT>), ggrid, block, 0, stream, p, tiles_x, tiles_y, n_tiles, grid_x);
         else if (strict) hipLaunchKernelGGL((render_lds_gated_kernel<TexT, false, true, TW, MINW, PF, LAYOUT>), ggrid, block, 0, stream, p, tiles_x, tiles_y, n_tiles, grid_x);

@@ -402,10 +402,11 @@ class MPI(nn.Module):
                      view_to_mpi: Optional[torch.Tensor] = None, check_last_plane: bool = False,
                      out_pm1: bool = False, want_transmittance: bool = False, c2w_mat=None, sphere_c=None,
                      status: Optional[torch.Tensor] = None, defer_status: bool = False, out: Optional[dict] = None,
-                     _in_autograd_fn: bool = False, frontal_hint: bool = False, tilted_hint: bool = False):
+                     _in_autograd_fn: bool = False, frontal_hint: bool = False, tilted_hint: bool = False, oblique_hint: bool = False):
         """Renders N views in one launch.  `frontal_hint`: the caller knows every camera axis to lie within 0.2 rad of the MPI normal
         (GMPI_FLAG_HINT_FRONTAL: advisory, only the kernel choice of small launches depends on it, never a result); `tilted_hint`: some
-        camera axis lies more than 0.53 rad off the normal (GMPI_FLAG_HINT_TILTED: keeps such launches off the strip kernel).
+        camera axis lies more than 0.53 rad off the normal (GMPI_FLAG_HINT_TILTED: keeps such launches off the strip kernel); `oblique_hint`: some
+        camera axis lies more than 0.35 rad off the normal (GMPI_FLAG_HINT_OBLIQUE: views that share an MPI then go to the tile kernel at once).
 
         rgba [M,D,4,Ht,Wt] (f32/bf16/f16, any outer strides, innermost contiguous), dhw [M,D,3],
         ray_dir [N,3,H,W], eye_pos [N,3], z_dir [N,3].  View n samples MPI `view_to_mpi[n]`; without it,
@@ -422,7 +423,7 @@ class MPI(nn.Module):
             # G-step of the reference (train.py:740-779): gradient w.r.t. the RGBA volume through the fused backward
             kwargs = dict(views_per_mpi=views_per_mpi, view_to_mpi=view_to_mpi, check_last_plane=check_last_plane,
                           out_pm1=out_pm1, want_transmittance=want_transmittance, c2w_mat=c2w_mat, sphere_c=sphere_c,
-                          status=status, defer_status=defer_status, out=out, frontal_hint=frontal_hint, tilted_hint=tilted_hint)
+                          status=status, defer_status=defer_status, out=out, frontal_hint=frontal_hint, tilted_hint=tilted_hint, oblique_hint=oblique_hint)
             color, depth, T, st = _RenderFunction.apply(rgba, self, dhw, ray_dir, eye_pos, z_dir, kwargs)
             return dict(color=color, depth=depth, T=T if want_transmittance else None, status=st)
         lib = _lib.load_library()
@@ -504,6 +505,8 @@ class MPI(nn.Module):
                 flags |= _lib.FLAG_HINT_FRONTAL
             if tilted_hint:
                 flags |= _lib.FLAG_HINT_TILTED
+            if oblique_hint:
+                flags |= _lib.FLAG_HINT_OBLIQUE
 
             p = _lib.GmpiRenderParams()
             p.struct_size = ctypes.sizeof(_lib.GmpiRenderParams)

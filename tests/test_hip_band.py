@@ -302,3 +302,54 @@ def test_frontal_hint_changes_no_result():
         for hint in (False, True):
             out = mpi.render_views(*args, check_last_plane=True, frontal_hint=hint)
             assert np.array_equal(out["color"].cpu().numpy(), orc["color"]) and np.array_equal(out["depth"].cpu().numpy(), orc["depth"]), hint
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_auto_renders_views_that_share_an_mpi_with_the_band_kernel_and_keeps_a_group_together(dtype):
+    """Round 6: a camera path over ONE MPI (views_per_mpi = 8, render_video.py:95-130) under GMPI_VARIANT_AUTO.  Every view within the band kernel's reach:
+    the band kernel renders the group (no gate word written).  One view beyond it: the table kernel hands the WHOLE group to the tile kernel (every view's
+    gate word carries the launch's generation) -- two kernels that each render a few views of the group lose to one that renders them all.  Either way, and
+    with GMPI_FLAG_HINT_OBLIQUE (the host knows a camera is more than 0.35 rad off the normal: tile kernel at once), the same pixels: strict-order mode
+    bit-identical to the oracle, default mode inside the bars."""
+    from ml_gmpi_amd import MPI, hip_mpi
+    from ml_gmpi_amd.renderer import MPIRenderer, PRESETS
+    lib = _lib().load_library()
+    dev = torch.device("cuda:0")
+    S, V, D = 512, 8, 5
+    bw = 128 if dtype == torch.float32 else 256
+    n_bands = V * ((S + bw - 1) // bw) * (S // 8)
+    assert n_bands >= lib.gmpi_query(10 if dtype == torch.float32 else 9)
+    kw = dict(PRESETS["FFHQ"])
+    kw.update(n_mpi_planes=D, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse", cam_sample_method="truncated_gaussian",
+              mpi_align_corners=True, use_confined_volume=True, device=torch.device("cpu"))
+    r = MPIRenderer(**kw)
+    r.set_cam(r.cam_fov, S, S)
+    rgba = torch.rand((1, D, 4, S, S), generator=torch.Generator().manual_seed(91)).to(dtype)
+    dhw = r.static_mpi_plane_dhws.reshape(1, -1, 3).contiguous()
+    for lim, want_gated in ((0.25, False), (0.5, True)):
+        cam = r.sample_cam_poses(V, 0, 0, 0, 0, False, given_yaws=torch.linspace(lim, -lim, V).view(-1, 1), given_pitches=torch.zeros(V, 1))
+        ray, eye, zd = torch.cat(cam[3]), torch.cat(cam[4]), torch.cat(cam[5])
+        orc = oracle.render(rgba.float(), dhw, ray, eye, zd, view_to_mpi=np.zeros(V, dtype=np.int32), threads=True)
+        for oblique in (False, True):
+            for strict in (True, False):
+                mpi = MPI(align_corners=True, variant="auto", strict_order=strict, range_check="touched", on_out_of_plane="raise")
+                args = [t.to(dev) for t in (rgba, dhw, ray, eye, zd)]
+                with torch.no_grad():
+                    mpi.render_views(*args, views_per_mpi=V, check_last_plane=True, want_transmittance=True, oblique_hint=oblique)   # (the workspace exists now)
+                    ws = hip_mpi.workspace_of(dev)
+                    if ws is not None:
+                        ws.zero_()
+                    out = mpi.render_views(*args, views_per_mpi=V, check_last_plane=True, want_transmittance=True, oblique_hint=oblique)
+                torch.cuda.synchronize()
+                got = {k: out[k].cpu().numpy() for k in ("color", "depth", "T")}
+                for k in got:
+                    if strict:
+                        assert np.array_equal(got[k], orc[k]), (lim, oblique, k, np.abs(got[k] - orc[k]).max())
+                    else:
+                        assert np.abs(got[k] - orc[k]).max() <= TOL, (lim, oblique, k)
+                if not oblique:   # which kernel rendered the group: the gate words behind the band headers of the workspace
+                    gate = hip_mpi.workspace_of(dev)[4 * n_bands:4 * (n_bands + V)].view(torch.int32).cpu().tolist()
+                    if want_gated:
+                        assert gate[0] != 0 and all(g == gate[0] for g in gate), gate
+                    else:
+                        assert all(g == 0 for g in gate), gate

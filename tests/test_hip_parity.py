@@ -240,7 +240,7 @@ def test_c_abi_rejects_bad_arguments():
     for name in ("rgba", "dhw", "ray_dir", "eye_pos", "z_dir", "rgb_out", "depth_out"):
         setattr(p, name, buf.data_ptr())
     p.rgba_stride[:] = [64, 64, 16, 4, 1]
-    for bit in (8, 16, 17, 18, 19, 24, 31):   # (bits 5, 6 = GMPI_FLAG_HINT_FRONTAL / _TILTED, bit 7 = GMPI_FLAG_GRAD_OVERWRITE: the backward's, ignored here)
+    for bit in (9, 16, 17, 18, 19, 24, 31):   # (bits 5, 6, 8 = GMPI_FLAG_HINT_FRONTAL / _TILTED / _OBLIQUE, bit 7 = GMPI_FLAG_GRAD_OVERWRITE: the backward's, ignored here)
         p.flags = L.FLAG_ALIGN_CORNERS | (1 << bit)
         assert lib.gmpi_mpi_render_launch(ctypes.byref(p), None) == -7, bit  # GMPI_E_FLAGS
     p.flags = L.FLAG_ALIGN_CORNERS

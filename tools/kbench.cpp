@@ -107,6 +107,9 @@ int main(int argc, char** argv) {
             bool tilted = false;
             for (int n = 0; n < N; ++n) tilted = tilted || zd[n * 3 + 2] < 0.86280707f;  // cos(0.53)
             if (tilted) p.flags |= GMPI_FLAG_HINT_TILTED;
+            bool oblique = false;   // (KB_NOHINT=1: a C host that does not know its cameras -- the device decides, group by group)
+            for (int n = 0; n < N; ++n) oblique = oblique || zd[n * 3 + 2] < 0.93937271f;  // cos(0.35)
+            if (oblique && !getenv("KB_NOHINT")) p.flags |= GMPI_FLAG_HINT_OBLIQUE;
         }
         CK(hipMemset(d_st, 0, 256)); CK(hipMemset(d_rgb, 0xff, npix * 12)); CK(hipMemset(d_dep, 0xff, npix * 4));
         int rc = launch(&p, nullptr);

@@ -83,3 +83,6 @@ kw.update(n_mpi_planes=96, plan_spatial_enlarge_factor=1.001, plane_distances_sa
 r = MPIRenderer(**kw)
 r.set_cam(r.cam_fov, 512, 512)
 dump("c4", r.sample_cam_poses(8, 0, 0, 0, 0, False, given_yaws=torch.linspace(0.5, -0.5, 8).view(-1, 1), given_pitches=torch.zeros(8, 1)))
+# ... and narrower sweeps of the same path (which kernel is best for views that share an MPI when every view fits the band kernel's boxes)
+for name, lim in (("c4n", 0.25), ("c4m", 0.35)):
+    dump(name, r.sample_cam_poses(8, 0, 0, 0, 0, False, given_yaws=torch.linspace(lim, -lim, 8).view(-1, 1), given_pitches=torch.zeros(8, 1)))
