@@ -198,6 +198,40 @@ def test_fuzz_band_kernel_and_auto_on_random_problems():
                 assert np.abs(fast[k] - orc[k]).max() <= bar, (i, cfg, variant, k, float(np.abs(fast[k] - orc[k]).max()))
 
 
+def test_fuzz_views_that_share_mpis_on_random_problems():
+    """Round 6: views that share MPIs (views_per_mpi > 1: camera paths) take AUTO's band path too -- the band kernel when every view of a group fits, the tile kernel
+    for a WHOLE group otherwise (the table kernel gates the group together).  Random sizes, textures, storage types, group sizes and poses (random draws, the
+    2-sigma corner and beyond: groups of every kind), with and without GMPI_FLAG_HINT_OBLIQUE: strict-order mode bit-identical to the oracle, default mode inside
+    the bars, for GMPI_VARIANT_AUTO and explicit GMPI_VARIANT_BAND."""
+    from ml_gmpi_amd import MPI
+    import os
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SHARED_SEED", 20261001)))
+    dev = torch.device("cuda:0")
+    for i in range(int(os.environ.get("FUZZ_SHARED_CASES", 16))):   # (a builder-side run with 150 cases and another seed: profiles/r06_fuzz.txt)
+        cfg, (vol, dhw, ray, eye, zd) = _fuzz_case_large(rng)
+        B = cfg["B"]
+        vpm = [v for v in (2, 3, 4, 6) if v <= B][int(rng.integers(0, len([v for v in (2, 3, 4, 6) if v <= B])))]
+        M = B // vpm                                   # (the reference's grouping is uniform: N = M x views_per_mpi, prepare_fake_data.py:58-63)
+        B = M * vpm
+        vol, dhw, ray, eye, zd = vol[:M].contiguous(), dhw[:M].contiguous(), ray[:B].contiguous(), eye[:B].contiguous(), zd[:B].contiguous()
+        v2m = np.arange(B, dtype=np.int32) // vpm
+        orc = oracle.render(vol.float(), dhw, ray, eye, zd, align_corners=cfg["ac"], view_to_mpi=v2m, threads=True)
+        args = [t.to(dev) for t in (vol, dhw, ray, eye, zd)]
+        for variant in ("auto", "band"):
+            for strict in (True, False):
+                for oblique in ((False, True) if variant == "auto" else (False,)):
+                    mpi = MPI(align_corners=cfg["ac"], variant=variant, strict_order=strict, range_check="touched", on_out_of_plane="raise")
+                    with torch.no_grad():
+                        out = mpi.render_views(*args, views_per_mpi=vpm, check_last_plane=False, want_transmittance=True, oblique_hint=oblique)
+                    torch.cuda.synchronize()
+                    for k, bar in (("color", 0.5 * TOL), ("depth", TOL), ("T", TOL)):
+                        got = out[k].cpu().numpy()
+                        if strict:
+                            assert np.array_equal(got, orc[k]), (i, cfg, vpm, variant, oblique, k, float(np.abs(got - orc[k]).max()))
+                        else:
+                            assert np.abs(got - orc[k]).max() <= bar, (i, cfg, vpm, variant, oblique, k, float(np.abs(got - orc[k]).max()))
+
+
 def test_fp16_texel_staging_of_the_strip_kernel():
     """16-bit volumes in default mode are staged as fp16 RGBA texels (render_wave.hip, HALF): exact for 2^-17 <= |v| <= 65280.
     (a) colours fp16 cannot represent (1e6, -3e5; alpha stays in [0,1], range check off as MPI.forward allows): the planes that

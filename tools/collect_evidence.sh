@@ -12,7 +12,7 @@ cp gpurun_out/prof_$T/trace/t_kernel_stats.csv profiles/${T}_cfg3_kernel_stats.c
 cp gpurun_out/prof_$T/train1024/trace/t_kernel_stats.csv profiles/${T}_train1024_kernel_stats.csv
 for f in bench_lines.jsonl default_bench.json train_lines.jsonl video_bench.json torchrun1_bench.json; do cp gpurun_out/${T}_$f profiles/${T}_$f; done
 {
-  echo "Round ${T#r0}, randomized parity runs on the final sources ($H), one MI355X (the evidence box of profiles/${T}_*; GPU tests on the same box: $(grep -E '^[0-9]+ passed' gpurun_out/${T}_pytest_gpu.txt | head -1), smoke ok):"
+  echo "Round ${T#r0}, randomized parity runs on the final sources ($H), one MI355X (the evidence box of profiles/${T}_*; GPU tests on the same box: $(grep -oE '[0-9]+ (passed|failed)[^=]*' gpurun_out/${T}_pytest_gpu.txt | head -1), smoke ok):"
   echo "tools/fuzz_gpu.py 500 606:"; tail -n 1 gpurun_out/${T}_fuzz_a.txt
   echo "FUZZ_LARGE=1 tools/fuzz_gpu.py 120 607 (launches large enough for AUTO's band path and its view sharing):"; tail -n 1 gpurun_out/${T}_fuzz_b.txt
   echo "tools/fuzz_backward_gpu.py 600 608 (the atomic tile kernel, 64 x 8 tiles, against the one-pixel-per-lane kernel):"; tail -n 1 gpurun_out/${T}_fuzz_bwd.txt
