@@ -636,14 +636,16 @@ __global__ __launch_bounds__(kNT, MINW) void render_lds_kernel(const KParams p, 
 // AUTO's fallback launch for the views the band kernel leaves (KParams::gate): usually NO view is left, and a grid of one workgroup per
 // tile of every view that only exits costs 17 us for BASELINE config 3 (8192 workgroups: the dispatch rate).  So the gated launch has a
 // fixed, small grid whose workgroups walk the virtual block indices round by round: 2 us when there is nothing to do.
-// The grid (round 6; profiles/r06_band_order.txt): about ONE round of resident workgroups and a multiple of 8 (a workgroup's virtual blocks stay on its XCD)
-// whose eighth is ODD -- 4 workgroups per CU with 16-bit volumes: 8 x 127 = 1016; 3 per CU with fp32 volumes (53 KB of LDS each): 8 x 95 = 760 (768: +8 %,
-// 1016: +22 % -- the last 256 run alone in a second round).  Odd, because views that share an MPI are interleaved per tile position (8 views: view =
-// (vblock / 8) % 8): a stride of 8 x 128 showed a workgroup the SAME view on every round, and two views of eight left to this kernel were rendered by a quarter
-// of the workgroups, four tiles each (0.645 ms).  Rounds 3-5 launched 1024 for both AND kept a byte per view in LDS, which took the fp32 instances over a third
-// of a CU's LDS: two workgroups per CU, 29 % slower than the plain tile kernel on the same tiles (below).  (Handing the tiles out by tickets -- an atomic counter
-// per XCD -- was built and measured: 512 returning atomics per counter serialise at more than 1 us each: 1.27 ms for what the plain tile kernel does in 0.545.)
-template <typename TexT> constexpr unsigned gated_grid() { return sizeof(TexT) == 4 ? 760u : 1016u; }
+// The grid (round 6; profiles/r06_band_order.txt): ONE round of resident workgroups -- 4 per CU with 16-bit volumes: 1024; 3 per CU with fp32 volumes (53 KB of
+// LDS each): 768 (1024 there ran its last 256 alone in a second round: +22 % on a launch whose eight views all came through the gate).  Views that SHARE an MPI
+// are interleaved per tile position (8 views: view = (vblock / 8) % 8), and a stride of 8 x 128 showed a workgroup the SAME view on every round -- two views of
+// eight left to this kernel were rendered by a quarter of the workgroups, four tiles each (0.645 ms): for such launches the grid is a multiple of 8 whose eighth
+// is ODD, 8 x 127 = 1016 / 8 x 95 = 760 (760 measured best there: 768 +8 %).  Everything else keeps the power of two: two gated views of 512^2 are 1024 tiles,
+// which 1016 workgroups would render in two rounds (0.2135 ms against 0.1725).  Rounds 3-5 launched 1024 for everything AND kept a byte per view in LDS, which took
+// the fp32 instances over a third of a CU's LDS: two workgroups per CU, 29 % slower than the plain tile kernel on the same tiles (below).  (Handing the tiles out
+// by tickets -- an atomic counter per XCD -- was built and measured: 512 returning atomics per counter serialise at more than 1 us each: 1.27 ms for what the plain
+// tile kernel does in 0.545.)
+template <typename TexT> constexpr unsigned gated_grid(bool shared) { return sizeof(TexT) == 4 ? (shared ? 760u : 768u) : (shared ? 1016u : 1024u); }
 constexpr int kGatedViews = 512;   // views whose gate a workgroup caches in LDS (kNT threads read one gate word each)
 template <typename TexT, bool AC, bool STRICT, int TW, int MINW, int PF, int LAYOUT>
 __global__ __launch_bounds__(kNT, MINW) void render_lds_gated_kernel(const KParams p, const int tiles_x, const int tiles_y, const int n_tiles,
@@ -704,7 +706,7 @@ static hipError_t launch_lds_t(const KParams& p, hipStream_t stream) {
     const dim3 grid(grid_x), block(kNT);
     const bool ac = p.flags & 1u, strict = p.flags & (1u << 4);
     if (p.gate != nullptr) {
-        unsigned gg = std::min(grid_x, gated_grid<TexT>());
+        unsigned gg = std::min(grid_x, gated_grid<TexT>(p.view_to_mpi == nullptr && p.views_per_mpi > 1));
 #ifdef GMPI_TUNE  // GMPI_TUNE_GGRID: the gated launch's grid (A/B)
         static const int env_gg = [] { const char* e = getenv("GMPI_TUNE_GGRID"); return e ? atoi(e) : 0; }();
         if (env_gg > 0) gg = std::min(grid_x, static_cast<unsigned>(env_gg));
