@@ -86,3 +86,11 @@ dump("c4", r.sample_cam_poses(8, 0, 0, 0, 0, False, given_yaws=torch.linspace(0.
 # ... and narrower sweeps of the same path (which kernel is best for views that share an MPI when every view fits the band kernel's boxes)
 for name, lim in (("c4n", 0.25), ("c4m", 0.35)):
     dump(name, r.sample_cam_poses(8, 0, 0, 0, 0, False, given_yaws=torch.linspace(lim, -lim, 8).view(-1, 1), given_pitches=torch.zeros(8, 1)))
+# ... and 4 views of 1024^2 that are ALL beyond the band kernel's reach (yaw 0.45) or alternate (0.45 / 0): the gated tile launch against the plain tile kernel
+kw = dict(PRESETS["FFHQ"])
+kw.update(n_mpi_planes=96, plan_spatial_enlarge_factor=1.001, plane_distances_sample_method="inverse", cam_sample_method="truncated_gaussian",
+          mpi_align_corners=True, use_confined_volume=True, device=torch.device("cpu"))
+r = MPIRenderer(**kw)
+r.set_cam(r.cam_fov, 1024, 1024)
+dump("p1024_y450", r.sample_cam_poses(4, 0, 0, 0, 0, False, given_yaws=torch.full((4, 1), 0.45), given_pitches=torch.zeros((4, 1))))
+dump("p1024_mix", r.sample_cam_poses(4, 0, 0, 0, 0, False, given_yaws=torch.tensor([[0.45], [0.0], [0.45], [0.0]]), given_pitches=torch.zeros((4, 1))))
