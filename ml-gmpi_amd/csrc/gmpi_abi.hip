@@ -286,6 +286,7 @@ constexpr int64_t kAutoBandMinF32 = 1024;  // fp32: bands of 128 x 8 pixels (at 
 // rounds 3-4's threshold of 512 bands: strict-order launches (never measured below it: the strip kernel keeps its 2^18..2^19-pixel range) and launches whose
 // caller says that some camera is tilted beyond 0.53 rad (a view the band kernel cannot stage then costs a table kernel and an empty band launch on top).
 constexpr int64_t kAutoBandMinUnmeasured = 512;
+constexpr int64_t kAutoBandMinShared = 1024, kAutoBandMinSharedF32 = 2048;   // views that share MPIs (config 4's launch, the size that was measured)
 
 // does GMPI_VARIANT_AUTO consider the band kernel for this launch (given a workspace and the band kernel's alignment preconditions)?
 static int64_t band_count(const KParams& p, int dtype) {
@@ -313,6 +314,10 @@ static bool auto_takes_band(const KParams& p, int dtype) {
     //  the tile kernel's 32 x 16 tiles fit such images better)
     if (static_cast<int64_t>(p.W) * 4 < cols * bw * 3 || static_cast<int64_t>(p.H) * 4 < rows * 8 * 3) return false;
     int64_t need = dtype == GMPI_DTYPE_F32 ? kAutoBandMinF32 : kAutoBandMin;
+    // (views that share MPIs: only launches of the size that was measured, config 4's -- 8 views of 512^2: 1024 bands of 256 x 8 pixels / 2048 of 128 x 8.  Small
+    //  shared launches belong to the tile kernel, whose interleaved tiles keep the one volume in the L2s: 8 views of 256^2 or 2 of 512^2 over a bf16 volume, 256 bands:
+    //  0.118 ms against the band kernel's 0.129 (frontal) / 0.143 (0.3 rad of yaw))
+    if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) need = dtype == GMPI_DTYPE_F32 ? kAutoBandMinSharedF32 : kAutoBandMinShared;
     if (dtype != GMPI_DTYPE_F32 && (p.flags & (GMPI_FLAG_STRICT_ORDER | GMPI_FLAG_HINT_TILTED)) != 0) need = kAutoBandMinUnmeasured;
     return band_count(p, dtype) >= need;
 }
@@ -351,9 +356,12 @@ int gmpi_mpi_render_launch(const GmpiRenderParams* params, void* stream) {
         // ... and beyond 0.53 rad of tilt (GMPI_FLAG_HINT_TILTED) the strip kernel's wave-private boxes overflow into half strips and the direct
         // gather: config 2 takes 0.25-0.77 ms instead of 0.16 where the tile kernel stays at 0.21 (profiles/r04_pose_distribution.txt)
         const bool tilted = (p.flags & GMPI_FLAG_HINT_TILTED) != 0;
+        // ... and views that SHARE MPIs (round 6): the tile kernel interleaves them per tile, the volume comes from HBM once per group -- 16-bit volumes, 8 views of
+        // 256^2 or 2 of 512^2 (2048 strips) under a frontal camera: 0.118 ms against the strip kernel's 0.145 (fp32 volumes: the strip kernel stays ahead, 0.130 / 0.152)
+        const bool shared = p.view_to_mpi == nullptr && p.views_per_mpi > 1;
         const bool small = strict ? (pixels <= (int64_t(1) << 19) && pixels > (int64_t(1) << 18))
                          : params->rgba_dtype == GMPI_DTYPE_F32 ? (strips <= 512 || (strips > 1536 && strips <= 2048 && !tilted))
-                                                                : (strips <= 512 || (strips <= 2048 && frontal));
+                                                                : (strips <= 512 || (strips <= 2048 && frontal && !shared));
         variant = (wave_ok && (small || !lds_ok)) ? GMPI_VARIANT_WAVE : lds_ok ? GMPI_VARIANT_LDS : GMPI_VARIANT_GATHER;
         // (a launch the band kernel takes -- below -- is not "small", whatever the hints say: 16-bit volumes reach the band threshold at exactly the
         //  2048 strips up to which a frontal hint would pick the strip kernel)
