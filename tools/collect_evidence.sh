@@ -18,5 +18,6 @@ for f in bench_lines.jsonl default_bench.json train_lines.jsonl video_bench.json
   echo "tools/fuzz_backward_gpu.py 600 608 (the atomic tile kernel, 64 x 8 tiles, against the one-pixel-per-lane kernel):"; tail -n 1 gpurun_out/${T}_fuzz_bwd.txt
   echo "FUZZ_BWD=gather tools/fuzz_backward_gpu.py 600 609 (the atomics-free pair against the one-pixel-per-lane kernel):"; tail -n 1 gpurun_out/${T}_fuzz_bwd_gather.txt
   echo "earlier in the round, other boxes and earlier sources: the same four commands on 9e2df0a9e673 and 5877118c7317 (all ok; backward worst 4.89e-06 / 5.55e-06 and 4.87e-06 / 7.12e-06); gather pair 400 cases worst 9.66e-06, 300 cases 2.04e-06; tile kernel 300-400 cases each on five builds, worst 8.0e-06 (gpurun_out/r6*/fuzz_backward*.txt)"
-} > profiles/${T}_fuzz.txt
+  grep -E '^(FUZZ_SHARED_CASES|Extended runs)' profiles/${T}_fuzz.txt 2>/dev/null || true   # (lines added by hand: runs outside the evidence call)
+} > profiles/${T}_fuzz.txt.new && mv profiles/${T}_fuzz.txt.new profiles/${T}_fuzz.txt
 python tools/status_table.py $T
