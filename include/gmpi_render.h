@@ -73,7 +73,8 @@ enum {
                                             of grad_rgba (no zero-fill needed); without the flag it reads, adds and writes back.  On the tile-kernel
                                             path (no workspace, or a launch the gather path does not take) the flag changes nothing: that path only
                                             ever ADDS, and the caller zero-fills as before.                                                      */
-    GMPI_FLAG_HINT_OBLIQUE = 1 << 8,     /* advisory (round 6), between the two: SOME view's camera axis is more than 0.35 rad off the MPI normal.  Only read for
+    GMPI_FLAG_HINT_OBLIQUE = 1 << 8,     /* advisory (round 6), between the two: SOME view's camera axis is more than 0.35 rad off the MPI normal.  Read (a) like
+                                            GMPI_FLAG_HINT_TILTED for 16-bit launches of 256-511 bands of 256 x 8 pixels (kept off the band kernel's two-kernel path), and (b) for
                                             launches whose views SHARE MPIs (views_per_mpi > 1: camera paths over one MPI) and that are large enough (from 1024 bands of 256 x 8 pixels
                                             over a 16-bit volume, 2048 of 128 x 8 over an fp32 one: 8 views of 512^2): without it GMPI_VARIANT_AUTO renders
                                             them with the band kernel -- 9 % (fp32) to 20 % (16-bit volumes) faster than the tile kernel when every view's texel

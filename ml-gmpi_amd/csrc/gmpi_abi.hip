@@ -318,7 +318,9 @@ static bool auto_takes_band(const KParams& p, int dtype) {
     //  shared launches belong to the tile kernel, whose interleaved tiles keep the one volume in the L2s: 8 views of 256^2 or 2 of 512^2 over a bf16 volume, 256 bands:
     //  0.118 ms against the band kernel's 0.129 (frontal) / 0.143 (0.3 rad of yaw))
     if (p.view_to_mpi == nullptr && p.views_per_mpi > 1) need = dtype == GMPI_DTYPE_F32 ? kAutoBandMinSharedF32 : kAutoBandMinShared;
-    if (dtype != GMPI_DTYPE_F32 && (p.flags & (GMPI_FLAG_STRICT_ORDER | GMPI_FLAG_HINT_TILTED)) != 0) need = kAutoBandMinUnmeasured;
+    // (round 6: GMPI_FLAG_HINT_OBLIQUE counts like _TILTED here -- a camera beyond 0.35 rad is one the band kernel cannot stage at these sizes: 2 views of 512^2 / 8 of
+    //  256^2 at 0.45 rad of yaw went through the table kernel, an empty band launch and the gated tile launch, 0.168-0.174 ms against the tile kernel's 0.141-0.145)
+    if (dtype != GMPI_DTYPE_F32 && (p.flags & (GMPI_FLAG_STRICT_ORDER | GMPI_FLAG_HINT_TILTED | GMPI_FLAG_HINT_OBLIQUE)) != 0) need = kAutoBandMinUnmeasured;
     return band_count(p, dtype) >= need;
 }
 
